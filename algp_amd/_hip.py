@@ -1,0 +1,360 @@
+"""ctypes binding of libalgp_hip.so (include/algp_hip.h).
+
+This is the only place the package touches native code.  There is no CPU
+fallback: if the library is missing, or no MI355X is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libalgp_hip.so')
+
+F32, F64 = 0, 1
+KERNEL_RBF, KERNEL_MATERN15 = 0, 1
+CRIT_ENTROPY, CRIT_MUTUAL_INFORMATION = 0, 1
+OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_OOM, ERR_STATE, ERR_NO_DEVICE = range(7)
+PROF = dict(kmat=0, gemm_chol=1, gemm_trsm=2, potrf_diag=3, trsv=4, rows=5, score=6, gemm_other=7)
+
+_c_ctx = C.c_void_p
+_i64p = C.POINTER(C.c_int64)
+_dblp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/algp_hip.h declares
+SIGNATURES = {
+    'algp_version': (C.c_int, []),
+    'algp_device_count': (C.c_int, []),
+    'algp_create': (C.c_int, [C.c_int, C.c_int, C.POINTER(_c_ctx)]),
+    'algp_destroy': (None, [_c_ctx]),
+    'algp_last_error': (C.c_char_p, [_c_ctx]),
+    'algp_last_pivot': (C.c_int64, [_c_ctx]),
+    'algp_dtype': (C.c_int, [_c_ctx]),
+    'algp_set_hypers': (C.c_int, [_c_ctx, C.c_int, C.c_int, _dblp, C.c_double, C.c_double]),
+    'algp_kernel_matrix': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                     C.c_void_p]),
+    'algp_set_pool': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64]),
+    'algp_set_pool_cov': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64]),
+    'algp_set_train': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'algp_factorize': (C.c_int, [_c_ctx]),
+    'algp_get_logdet': (C.c_int, [_c_ctx, _dblp]),
+    'algp_get_entropy': (C.c_int, [_c_ctx, _dblp]),
+    'algp_get_alpha': (C.c_int, [_c_ctx, C.c_void_p]),
+    'algp_get_factor': (C.c_int, [_c_ctx, C.c_void_p]),
+    'algp_get_mll': (C.c_int, [_c_ctx, _dblp]),
+    'algp_set_candidates': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_int, C.c_void_p]),
+    'algp_solve_candidates': (C.c_int, [_c_ctx]),
+    'algp_get_posterior': (C.c_int, [_c_ctx, C.c_void_p, C.c_void_p]),
+    'algp_get_posterior_cov': (C.c_int, [_c_ctx, C.c_void_p, _dblp]),
+    'algp_posterior_mean': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p]),
+    'algp_scores': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int]),
+    'algp_argmax': (C.c_int, [_c_ctx, _i64p, _i64p, _dblp]),
+    'algp_commit_pick': (C.c_int, [_c_ctx, C.c_int64, C.c_double, C.c_double]),
+    'algp_greedy': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_int, _i64p, _i64p, _dblp]),
+    'algp_entropy_from_cov': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, _dblp]),
+    'algp_set_entropy': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p, _dblp]),
+    'algp_set_inverse_diag': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p, C.c_void_p, _dblp]),
+    'algp_cholesky': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, C.c_void_p, _dblp]),
+    'algp_gemm_nt': (C.c_int, [_c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_void_p,
+                               C.c_double, C.c_void_p, C.c_void_p]),
+    'algp_trsm_right_lt': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    'algp_selftest_mfma': (C.c_int, [_c_ctx, C.POINTER(C.c_int)]),
+    'algp_sync': (C.c_int, [_c_ctx]),
+    'algp_device_bytes': (C.c_int64, [_c_ctx]),
+    'algp_prof_enable': (C.c_int, [_c_ctx, C.c_int]),
+    'algp_prof_reset': (C.c_int, [_c_ctx]),
+    'algp_prof_get': (C.c_int, [_c_ctx, C.c_int, _dblp, _dblp, _dblp, _i64p]),
+}
+
+_lib = None
+
+
+class AlgpError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'algp_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+def load():
+    """dlopen the library and bind every declared symbol.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(make -C algp_amd/csrc); there is no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i64(a):
+    return None if a is None else a.ctypes.data_as(_i64p)
+
+
+class Context(object):
+    """One GPU context (algp_ctx).  dtype: np.float32 or np.float64."""
+
+    def __init__(self, dtype=np.float64, device=0):
+        self.lib = load()
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError('dtype must be float32 or float64')
+        h = _c_ctx()
+        rc = self.lib.algp_create(int(device), F64 if self.dtype == np.float64 else F32, C.byref(h))
+        if rc == ERR_NO_DEVICE:
+            raise AlgpError(rc, 'no HIP device visible: algp_amd needs an MI355X (gfx950); there is no CPU fallback')
+        if rc != OK:
+            raise AlgpError(rc, 'algp_create failed')
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.algp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers --------------------------------------------------------
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self.lib.algp_last_error(self.h).decode('utf-8', 'replace')
+        if rc == ERR_NOT_PD:
+            err = np.linalg.LinAlgError(msg)          # reference: LinAlgError from inv (utils.py:300)
+            err.pivot = int(self.lib.algp_last_pivot(self.h))
+            raise err
+        if rc in (ERR_BAD_ARG, ERR_STATE):
+            raise ValueError(msg)
+        if rc == ERR_OOM:
+            raise MemoryError(msg)
+        raise AlgpError(rc, msg)
+
+    def _arr(self, a, shape=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if shape is not None and a.shape != tuple(shape):
+            raise ValueError('expected shape %s, got %s' % (tuple(shape), a.shape))
+        return a
+
+    @staticmethod
+    def _idx(a):
+        return np.ascontiguousarray(a, dtype=np.int64).reshape(-1)
+
+    # -- hypers / kernel matrix -------------------------------------------
+    def set_hypers(self, log_lengthscale, log_outputscale, log_noise, kernel=KERNEL_RBF):
+        ls = np.ascontiguousarray(np.atleast_1d(log_lengthscale), dtype=np.float64)
+        self.D = len(ls)
+        self._check(self.lib.algp_set_hypers(self.h, int(kernel), len(ls), ls.ctypes.data_as(_dblp),
+                                             float(log_outputscale), float(log_noise)))
+
+    def kernel_matrix(self, x1, x2=None, diag_add=None, add_likelihood_var=False):
+        x1 = self._arr(x1)
+        x1 = x1.reshape(len(x1), -1)
+        n1 = x1.shape[0]
+        if x2 is None:
+            n2, x2p = n1, None
+        else:
+            x2 = self._arr(x2)
+            x2 = x2.reshape(len(x2), -1)
+            n2, x2p = x2.shape[0], _ptr(x2)
+        d = None if diag_add is None else self._arr(diag_add, (n1,))
+        out = np.empty((n1, n2), dtype=self.dtype)
+        self._check(self.lib.algp_kernel_matrix(self.h, _ptr(x1), n1, x2p, n2, _ptr(d), int(bool(add_likelihood_var)),
+                                                _ptr(out)))
+        return out
+
+    # -- pool / train / factor -----------------------------------------------
+    def set_pool(self, x):
+        x = self._arr(x)
+        x = x.reshape(len(x), -1)
+        self.n_pool = x.shape[0]
+        self._check(self.lib.algp_set_pool(self.h, _ptr(x), x.shape[0]))
+
+    def set_pool_cov(self, cov):
+        cov = self._arr(cov)
+        if cov.ndim != 2 or cov.shape[0] != cov.shape[1]:
+            raise ValueError('cov must be square')
+        self.n_pool = cov.shape[0]
+        self._check(self.lib.algp_set_pool_cov(self.h, _ptr(cov), cov.shape[0]))
+
+    def set_train(self, idx, y, var=None):
+        idx = self._idx(idx)
+        y = self._arr(y, (len(idx),))
+        v = None if var is None else self._arr(var, (len(idx),))
+        self.N = len(idx)
+        self._check(self.lib.algp_set_train(self.h, _i64(idx), len(idx), _ptr(y), _ptr(v)))
+
+    def factorize(self):
+        self._check(self.lib.algp_factorize(self.h))
+
+    def _get_double(self, fn):
+        v = C.c_double()
+        self._check(fn(self.h, C.byref(v)))
+        return v.value
+
+    def logdet(self):
+        return self._get_double(self.lib.algp_get_logdet)
+
+    def entropy(self):
+        return self._get_double(self.lib.algp_get_entropy)
+
+    def mll(self):
+        return self._get_double(self.lib.algp_get_mll)
+
+    def alpha(self):
+        out = np.empty(self.N, dtype=self.dtype)
+        self._check(self.lib.algp_get_alpha(self.h, _ptr(out)))
+        return out
+
+    def factor(self):
+        out = np.empty((self.N, self.N), dtype=self.dtype)
+        self._check(self.lib.algp_get_factor(self.h, _ptr(out)))
+        return out
+
+    # -- candidates ----------------------------------------------------------
+    def set_candidates(self, idx, prior_includes_noise=True, extra_var=None):
+        idx = self._idx(idx)
+        e = None if extra_var is None else self._arr(extra_var, (len(idx),))
+        self.M = len(idx)
+        self._check(self.lib.algp_set_candidates(self.h, _i64(idx), len(idx), int(bool(prior_includes_noise)), _ptr(e)))
+
+    def solve_candidates(self):
+        self._check(self.lib.algp_solve_candidates(self.h))
+
+    def posterior(self, want_var=True):
+        mu = np.empty(self.M, dtype=self.dtype)
+        var = np.empty(self.M, dtype=self.dtype) if want_var else None
+        self._check(self.lib.algp_get_posterior(self.h, _ptr(mu), _ptr(var)))
+        return (mu, var) if want_var else mu
+
+    def posterior_cov(self, want_cov=True, want_mi=False):
+        cov = np.empty((self.M, self.M), dtype=self.dtype) if want_cov else None
+        mi = C.c_double()
+        self._check(self.lib.algp_get_posterior_cov(self.h, _ptr(cov), C.byref(mi) if want_mi else None))
+        return cov, (mi.value if want_mi else None)
+
+    def posterior_mean(self, idx):
+        idx = self._idx(idx)
+        mu = np.empty(len(idx), dtype=self.dtype)
+        self._check(self.lib.algp_posterior_mean(self.h, _i64(idx), len(idx), _ptr(mu)))
+        return mu
+
+    # -- greedy ----------------------------------------------------------------
+    def scores(self, criterion, static_std, mobile_std, out_device_ptr=None):
+        if out_device_ptr is not None:
+            self._check(self.lib.algp_scores(self.h, int(criterion), float(static_std), float(mobile_std),
+                                             C.c_void_p(int(out_device_ptr)), 1))
+            return None
+        out = np.empty(self.M, dtype=np.float64)
+        self._check(self.lib.algp_scores(self.h, int(criterion), float(static_std), float(mobile_std), _ptr(out), 0))
+        return out
+
+    def argmax(self):
+        pos, pool, val = C.c_int64(), C.c_int64(), C.c_double()
+        self._check(self.lib.algp_argmax(self.h, C.byref(pos), C.byref(pool), C.byref(val)))
+        return pos.value, pool.value, val.value
+
+    def commit_pick(self, pool_idx, static_std, mobile_std):
+        self._check(self.lib.algp_commit_pick(self.h, int(pool_idx), float(static_std), float(mobile_std)))
+
+    def greedy(self, criterion, static_std, mobile_std, k, forced_picks=None, want_utilities=False):
+        picks = np.empty(k, dtype=np.int64)
+        ut = np.empty((k, self.M), dtype=np.float64) if want_utilities else None
+        f = None if forced_picks is None else self._idx(forced_picks)
+        if f is not None and len(f) != k:
+            raise ValueError('forced_picks must have k entries')
+        self._check(self.lib.algp_greedy(self.h, int(criterion), float(static_std), float(mobile_std), int(k), _i64(f),
+                                         _i64(picks), None if ut is None else ut.ctypes.data_as(_dblp)))
+        return (picks, ut) if want_utilities else picks
+
+    # -- entropies ---------------------------------------------------------------
+    def entropy_from_cov(self, cov):
+        cov = self._arr(cov)
+        k = cov.shape[0]
+        v = C.c_double()
+        self._check(self.lib.algp_entropy_from_cov(self.h, _ptr(cov), k, C.byref(v)))
+        return v.value
+
+    def set_entropy(self, idx, var=None):
+        idx = self._idx(idx)
+        vv = None if var is None else self._arr(var, (len(idx),))
+        v = C.c_double()
+        self._check(self.lib.algp_set_entropy(self.h, _i64(idx), len(idx), _ptr(vv), C.byref(v)))
+        return v.value
+
+    def set_inverse_diag(self, idx, var=None):
+        idx = self._idx(idx)
+        vv = None if var is None else self._arr(var, (len(idx),))
+        out = np.empty(len(idx), dtype=self.dtype)
+        v = C.c_double()
+        self._check(self.lib.algp_set_inverse_diag(self.h, _i64(idx), len(idx), _ptr(vv), _ptr(out), C.byref(v)))
+        return out, v.value
+
+    # -- dense building blocks ---------------------------------------------------
+    def cholesky(self, A):
+        A = self._arr(A)
+        n = A.shape[0]
+        L = np.empty((n, n), dtype=self.dtype)
+        ld = C.c_double()
+        self._check(self.lib.algp_cholesky(self.h, _ptr(A), n, _ptr(L), C.byref(ld)))
+        return L, ld.value
+
+    def gemm_nt(self, A, B, alpha=1.0, beta=0.0, Cm=None):
+        A, B = self._arr(A), self._arr(B)
+        m, k = A.shape
+        n = B.shape[0]
+        if B.shape[1] != k:
+            raise ValueError('inner dimensions differ')
+        Cm = None if Cm is None else self._arr(Cm, (m, n))
+        D = np.empty((m, n), dtype=self.dtype)
+        self._check(self.lib.algp_gemm_nt(self.h, m, n, k, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(Cm), _ptr(D)))
+        return D
+
+    def trsm_right_lt(self, L, B):
+        L, B = self._arr(L), self._arr(B)
+        n = L.shape[0]
+        m = B.shape[0]
+        X = np.empty((m, n), dtype=self.dtype)
+        self._check(self.lib.algp_trsm_right_lt(self.h, _ptr(L), n, _ptr(B), m, _ptr(X)))
+        return X
+
+    def selftest_mfma(self):
+        v = C.c_int()
+        self._check(self.lib.algp_selftest_mfma(self.h, C.byref(v)))
+        return v.value
+
+    # -- misc ----------------------------------------------------------------------
+    def sync(self):
+        self._check(self.lib.algp_sync(self.h))
+
+    def device_bytes(self):
+        return int(self.lib.algp_device_bytes(self.h))
+
+    def prof_enable(self, on=True):
+        self._check(self.lib.algp_prof_enable(self.h, int(bool(on))))
+
+    def prof_reset(self):
+        self._check(self.lib.algp_prof_reset(self.h))
+
+    def prof_get(self, klass):
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        k = PROF[klass] if isinstance(klass, str) else int(klass)
+        self._check(self.lib.algp_prof_get(self.h, k, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
+        return dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)
+
+
+def device_count():
+    return int(load().algp_device_count())

@@ -1,0 +1,1006 @@
+// api.hip -- extern "C" entry points of libalgp_hip.so (declared in include/algp_hip.h) and the
+// host-side orchestration of the device kernels.  No torch types, no CPU arithmetic fallback:
+// every numeric result comes from the HIP kernels in this directory.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "vecops.h"
+
+using namespace algp;
+
+namespace algp {
+
+int fail(algp_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+int ensure(algp_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return ALGP_OK;
+    if (bytes == 0) bytes = 256;
+    if (b.p) {
+        hipStreamSynchronize(c->stream);
+        hipFree(b.p);
+        c->dev_bytes -= (int64_t)b.cap;
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = (bytes + 255) / 256 * 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        (void)hipGetLastError();
+        return fail(c, ALGP_ERR_OOM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    c->dev_bytes += (int64_t)want;
+    return ALGP_OK;
+}
+
+static void release(algp_ctx* c, DevBuf& b) {
+    if (b.p) {
+        hipFree(b.p);
+        c->dev_bytes -= (int64_t)b.cap;
+    }
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+static hipEvent_t get_event(algp_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+// Profiling: one event pair per scope on the ctx stream; flops/bytes are the ALGORITHMIC figures
+// of the launch (DESIGN.md "measurement").  Nested scopes: only the outermost records.
+static thread_local int prof_depth = 0;
+void prof_begin(algp_ctx* c, int klass, double flops, double bytes) {
+    if (!c->prof_on) return;
+    if (prof_depth++ > 0) return;
+    PendingEvent pe;
+    pe.a = get_event(c);
+    pe.b = get_event(c);
+    pe.klass = klass;
+    c->prof[klass].flops += flops;
+    c->prof[klass].bytes += bytes;
+    c->prof[klass].launches += 1;
+    hipEventRecord(pe.a, c->stream);
+    c->pending.push_back(pe);
+}
+void prof_end(algp_ctx* c) {
+    if (!c->prof_on) return;
+    if (--prof_depth > 0) return;
+    hipEventRecord(c->pending.back().b, c->stream);
+}
+void prof_collect(algp_ctx* c) {
+    for (auto& pe : c->pending) {
+        hipEventSynchronize(pe.b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, pe.a, pe.b);
+        c->prof[pe.klass].ms += ms;
+        c->event_pool.push_back(pe.a);
+        c->event_pool.push_back(pe.b);
+    }
+    c->pending.clear();
+}
+
+}  // namespace algp
+
+// ---------------------------------------------------------------------------------------------
+// typed implementation
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int SC_LOGDET = 0;     // slots (doubles) of ctx->scal
+constexpr int SC_INFO = 1;       // int stored in a double slot
+constexpr int SC_AUXLOGDET = 2;
+constexpr int SC_AUXINFO = 3;
+constexpr int SC_AMAXV = 4;
+constexpr int SC_AMAXI = 5;
+constexpr int SC_PROBE = 6;
+constexpr int SC_COUNT = 32;
+
+KmatSrc make_src(algp_ctx* c) {
+    KmatSrc s;
+    s.Xs = c->Xs.p;
+    s.Cp = c->pool_is_cov ? c->Cp.p : nullptr;
+    s.n_pool = c->n_pool;
+    s.DP = c->hyp.DP;
+    s.kernel = c->hyp.kernel;
+    s.outputscale = c->hyp.outputscale;
+    s.noise = c->hyp.noise;
+    return s;
+}
+
+int sync(algp_ctx* c) {
+    ALGP_HIP(hipStreamSynchronize(c->stream));
+    return ALGP_OK;
+}
+
+template <typename T>
+struct Impl {
+    static T* p(DevBuf& b) { return (T*)b.p; }
+
+    static int rescale_pool(algp_ctx* c) {
+        if (c->pool_is_cov || c->n_pool == 0 || !c->hyp.set) return ALGP_OK;
+        ALGP_TRY(ensure(c, c->Xs, sizeof(T) * c->n_pool * c->hyp.DP));
+        return scale_coords_launch<T>(c, (const T*)c->Xraw.p, c->n_pool, p(c->Xs));
+    }
+
+    static int kernel_matrix(algp_ctx* c, const void* x1, int64_t n1, const void* x2, int64_t n2, const void* diag_add,
+                             int add_lik, void* out) {
+        const int D = c->hyp.D, DP = c->hyp.DP;
+        const bool sym = (x2 == nullptr);
+        if (sym) n2 = n1;
+        if (n1 == 0 || n2 == 0) return ALGP_OK;
+        const int64_t ldo = round_up(n2, 4);
+        DevBuf raw1, raw2, s1, s2, dv, o;
+        int rc = ALGP_OK;
+        auto cleanup = [&]() { release(c, raw1); release(c, raw2); release(c, s1); release(c, s2); release(c, dv); release(c, o); };
+#define KM_TRY(x) do { rc = (x); if (rc != ALGP_OK) { cleanup(); return rc; } } while (0)
+#define KM_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(c, ALGP_ERR_HIP, hipGetErrorString(e_)); } } while (0)
+        KM_TRY(ensure(c, raw1, sizeof(T) * n1 * D));
+        KM_TRY(ensure(c, s1, sizeof(T) * n1 * DP));
+        KM_HIP(hipMemcpyAsync(raw1.p, x1, sizeof(T) * n1 * D, hipMemcpyHostToDevice, c->stream));
+        KM_TRY(scale_coords_launch<T>(c, (const T*)raw1.p, n1, (T*)s1.p));
+        if (!sym) {
+            KM_TRY(ensure(c, raw2, sizeof(T) * n2 * D));
+            KM_TRY(ensure(c, s2, sizeof(T) * n2 * DP));
+            KM_HIP(hipMemcpyAsync(raw2.p, x2, sizeof(T) * n2 * D, hipMemcpyHostToDevice, c->stream));
+            KM_TRY(scale_coords_launch<T>(c, (const T*)raw2.p, n2, (T*)s2.p));
+        }
+        if (sym && diag_add) {
+            KM_TRY(ensure(c, dv, sizeof(T) * n1));
+            KM_HIP(hipMemcpyAsync(dv.p, diag_add, sizeof(T) * n1, hipMemcpyHostToDevice, c->stream));
+        }
+        KM_TRY(ensure(c, o, sizeof(T) * n1 * ldo));
+        KM_TRY(kmat_xy_launch<T>(c, (const T*)s1.p, n1, sym ? nullptr : (const T*)s2.p, n2, sym ? 1 : 0,
+                                 (sym && diag_add) ? (const T*)dv.p : nullptr, (sym && add_lik) ? c->hyp.noise : 0.0,
+                                 (T*)o.p, ldo));
+        KM_HIP(hipMemcpy2DAsync(out, sizeof(T) * n2, o.p, sizeof(T) * ldo, sizeof(T) * n2, n1, hipMemcpyDeviceToHost,
+                                c->stream));
+        KM_HIP(hipStreamSynchronize(c->stream));
+        cleanup();
+#undef KM_TRY
+#undef KM_HIP
+        return ALGP_OK;
+    }
+
+    static int set_pool(algp_ctx* c, const void* x, int64_t n) {
+        const int D = c->hyp.D;
+        ALGP_TRY(ensure(c, c->Xraw, sizeof(T) * n * D));
+        ALGP_HIP(hipMemcpyAsync(c->Xraw.p, x, sizeof(T) * n * D, hipMemcpyHostToDevice, c->stream));
+        c->n_pool = n;
+        c->pool_is_cov = false;
+        ALGP_TRY(rescale_pool(c));
+        return sync(c);
+    }
+
+    static int set_pool_cov(algp_ctx* c, const void* cov, int64_t n) {
+        ALGP_TRY(ensure(c, c->Cp, sizeof(T) * n * n));
+        ALGP_HIP(hipMemcpyAsync(c->Cp.p, cov, sizeof(T) * n * n, hipMemcpyHostToDevice, c->stream));
+        c->n_pool = n;
+        c->pool_is_cov = true;
+        return sync(c);
+    }
+
+    static int set_train(algp_ctx* c, const int64_t* idx, int64_t N, const void* y, const void* var) {
+        const int64_t Npad = round_up(std::max<int64_t>(N, 1), NB);
+        c->N = N;
+        c->Npad = Npad;
+        c->train_idx.assign(idx, idx + N);
+        c->pos_in_train.assign(c->n_pool, -1);
+        for (int64_t i = 0; i < N; ++i) c->pos_in_train[idx[i]] = i;
+        double ybar = 0;
+        const T* yt = (const T*)y;
+        for (int64_t i = 0; i < N; ++i) ybar += (double)yt[i];
+        ybar = N > 0 ? ybar / (double)N : 0.0;
+        c->ybar = ybar;
+        std::vector<T> y0(Npad, (T)0), vv(Npad, (T)0);
+        for (int64_t i = 0; i < N; ++i) y0[i] = (T)((double)yt[i] - ybar);
+        if (var)
+            for (int64_t i = 0; i < N; ++i) vv[i] = ((const T*)var)[i];
+        ALGP_TRY(ensure(c, c->Aidx, sizeof(int64_t) * Npad));
+        ALGP_TRY(ensure(c, c->y0, sizeof(T) * Npad));
+        ALGP_TRY(ensure(c, c->varA, sizeof(T) * Npad));
+        if (N > 0) ALGP_HIP(hipMemcpyAsync(c->Aidx.p, idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemcpyAsync(c->y0.p, y0.data(), sizeof(T) * Npad, hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemcpyAsync(c->varA.p, vv.data(), sizeof(T) * Npad, hipMemcpyHostToDevice, c->stream));
+        ALGP_TRY(sync(c));   // host vectors go out of scope
+        c->factored = false;
+        c->solved = false;
+        return ALGP_OK;
+    }
+
+    // factor an npad x npad matrix already resident in A; returns logdet; NOT_PD -> error with pivot
+    static int factor_resident(algp_ctx* c, T* A, int64_t n, int64_t npad, T* invD, int slot_logdet, int slot_info,
+                               double* logdet) {
+        double* sc = (double*)c->scal.p;
+        ALGP_HIP(hipMemsetAsync(sc + slot_logdet, 0, 2 * sizeof(double), c->stream));
+        ALGP_TRY(cholesky_blocked<T>(c, A, npad, npad, invD, sc + slot_logdet, (int*)(sc + slot_info)));
+        double host[2];
+        ALGP_HIP(hipMemcpyAsync(host, sc + slot_logdet, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        int info;
+        memcpy(&info, &host[1], sizeof(int));
+        if (info != 0) {
+            c->pivot = info;
+            return fail(c, ALGP_ERR_NOT_PD,
+                        "matrix is not positive definite: non-positive pivot at index " + std::to_string(info) +
+                            " (1-based) of " + std::to_string(n));
+        }
+        *logdet = host[0];
+        return ALGP_OK;
+    }
+
+    static int factorize(algp_ctx* c) {
+        const int64_t N = c->N, Npad = c->Npad;
+        c->factored = false;
+        c->solved = false;
+        ALGP_TRY(ensure(c, c->L, sizeof(T) * Npad * Npad));
+        ALGP_TRY(ensure(c, c->invD, sizeof(T) * Npad * NB));
+        ALGP_TRY(ensure(c, c->z, sizeof(T) * Npad));
+        ALGP_TRY(ensure(c, c->alpha, sizeof(T) * Npad));
+        KmatSrc s = make_src(c);
+        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p, N, Npad, (const int64_t*)c->Aidx.p, N, Npad,
+                                (const T*)c->varA.p, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->L), Npad));
+        double ld = 0;
+        ALGP_TRY(factor_resident(c, p(c->L), N, Npad, p(c->invD), SC_LOGDET, SC_INFO, &ld));
+        c->logdet = ld;
+        ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
+        ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, Npad, p(c->invD), p(c->z)));
+        ALGP_HIP(hipMemcpyAsync(c->alpha.p, c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
+        ALGP_TRY(trsv_backward<T>(c, p(c->L), Npad, Npad, p(c->invD), p(c->alpha)));
+        std::vector<T> zh(Npad);
+        ALGP_HIP(hipMemcpyAsync(zh.data(), c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        double q = 0;
+        for (int64_t i = 0; i < N; ++i) q += (double)zh[i] * (double)zh[i];
+        c->yalpha = q;    // y0' S^-1 y0 = |L^-1 y0|^2
+        c->factored = true;
+        return ALGP_OK;
+    }
+
+    static int set_candidates(algp_ctx* c, const int64_t* idx, int64_t M, int prior_noise, const void* extra) {
+        if (c->pool_is_cov && !prior_noise)
+            return fail(c, ALGP_ERR_BAD_ARG, "an explicit pool covariance carries sigma_n^2 on its diagonal: prior_includes_noise must be 1");
+        const int64_t Mpad = round_up(std::max<int64_t>(M, 1), NB);
+        c->M = M;
+        c->Mpad = Mpad;
+        c->prior_noise = prior_noise;
+        c->cand_idx.assign(idx, idx + M);
+        c->cand_pos.assign(c->n_pool, -1);
+        for (int64_t j = 0; j < M; ++j) c->cand_pos[idx[j]] = j;
+        ALGP_TRY(ensure(c, c->Cidx, sizeof(int64_t) * Mpad));
+        if (M > 0) ALGP_HIP(hipMemcpyAsync(c->Cidx.p, idx, sizeof(int64_t) * M, hipMemcpyHostToDevice, c->stream));
+        if (extra) {
+            ALGP_TRY(ensure(c, c->cextra, sizeof(T) * Mpad));
+            ALGP_HIP(hipMemcpyAsync(c->cextra.p, extra, sizeof(T) * M, hipMemcpyHostToDevice, c->stream));
+        } else {
+            release(c, c->cextra);
+        }
+        ALGP_TRY(sync(c));
+        c->solved = false;
+        return ALGP_OK;
+    }
+
+    static int solve_candidates(algp_ctx* c) {
+        if (!c->factored) return fail(c, ALGP_ERR_STATE, "solve_candidates: call algp_factorize first");
+        const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad;
+        const int64_t ldv = Npad + MAX_APPEND;
+        c->ldv = ldv;
+        c->solved = false;
+        ALGP_TRY(ensure(c, c->Vt, sizeof(T) * Mpad * ldv));
+        ALGP_TRY(ensure(c, c->dstat, sizeof(T) * Mpad));
+        ALGP_TRY(ensure(c, c->mu, sizeof(T) * Mpad));
+        ALGP_TRY(ensure(c, c->tvec, sizeof(T) * 2 * Mpad));
+        ALGP_TRY(ensure(c, c->alive, Mpad));
+        ALGP_TRY(ensure(c, c->scores, sizeof(double) * Mpad));
+        ALGP_TRY(ensure(c, c->lrow, sizeof(T) * ldv));
+        ALGP_TRY(ensure(c, c->prevrows, sizeof(T) * MAX_APPEND * ldv));
+        {
+            // greedy semantics: a candidate that is a train site is the unit vector e_pos (its
+            // noise changes); predictive semantics: it is an ordinary point at the same location
+            std::vector<int> kind(Mpad, -1);
+            if (c->prior_noise)
+                for (int64_t j = 0; j < M; ++j) kind[j] = (int)c->pos_in_train[c->cand_idx[j]];
+            ALGP_TRY(ensure(c, c->ckind, sizeof(int) * Mpad));
+            ALGP_HIP(hipMemcpyAsync(c->ckind.p, kind.data(), sizeof(int) * Mpad, hipMemcpyHostToDevice, c->stream));
+            ALGP_TRY(sync(c));
+        }
+        KmatSrc s = make_src(c);
+        // B^T: row j = C[cand_j, A] (ordinary) or e_pos (train-site candidate); zero padding
+        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Aidx.p, N, ldv, nullptr, 0,
+                                c->prior_noise ? (const int*)c->ckind.p : nullptr, 0, p(c->Vt), ldv));
+        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldv, p(c->L), Npad, Npad, p(c->invD)));
+        T* ss = p(c->tvec);
+        T* dot = ss + Mpad;
+        ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), M, ldv, Npad, p(c->z), ss, dot));
+        const T prior = (T)(c->hyp.outputscale + (c->prior_noise ? c->hyp.noise : 0.0));
+        ALGP_TRY(cand_finalize_launch<T>(c, M, (const int*)c->ckind.p, (const int64_t*)c->Cidx.p,
+                                         c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, prior,
+                                         c->cextra.p ? (const T*)c->cextra.p : nullptr, ss, dot, (T)c->ybar, p(c->dstat),
+                                         p(c->mu), (unsigned char*)c->alive.p));
+        ALGP_TRY(sync(c));
+        c->ncols = Npad;
+        c->picks.clear();
+        c->solved = true;
+        return ALGP_OK;
+    }
+
+    static int get_posterior(algp_ctx* c, void* mu, void* var) {
+        if (!c->solved) return fail(c, ALGP_ERR_STATE, "get_posterior: call algp_solve_candidates first");
+        if (mu) ALGP_HIP(hipMemcpyAsync(mu, c->mu.p, sizeof(T) * c->M, hipMemcpyDeviceToHost, c->stream));
+        if (var) ALGP_HIP(hipMemcpyAsync(var, c->dstat.p, sizeof(T) * c->M, hipMemcpyDeviceToHost, c->stream));
+        return sync(c);
+    }
+
+    static int get_posterior_cov(algp_ctx* c, void* cov_out, double* mi_out) {
+        if (!c->solved) return fail(c, ALGP_ERR_STATE, "get_posterior_cov: call algp_solve_candidates first");
+        if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "get_posterior_cov needs a coordinate pool");
+        const int64_t M = c->M, Mpad = c->Mpad;
+        ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Mpad * Mpad));
+        ALGP_TRY(ensure(c, c->auxW, sizeof(T) * Mpad * Mpad));
+        ALGP_TRY(ensure(c, c->auxInv, sizeof(T) * Mpad * NB));
+        KmatSrc s = make_src(c);
+        const T* extra = c->cextra.p ? (const T*)c->cextra.p : nullptr;
+        // cov_xx = K_xx + diag(test_var)   (utils.py:297; no likelihood noise)
+        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Cidx.p, M, Mpad, extra, 0,
+                                nullptr, 1, p(c->auxA), Mpad));
+        // cov = cov_xx - V^T V  (utils.py:305)
+        ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, Mpad, Mpad, c->Npad, (T)-1, p(c->Vt), c->ldv, p(c->Vt),
+                                   c->ldv, (T)1, p(c->auxA), Mpad, p(c->auxW), Mpad, 0));
+        if (cov_out)
+            ALGP_HIP(hipMemcpy2DAsync(cov_out, sizeof(T) * M, c->auxW.p, sizeof(T) * Mpad, sizeof(T) * M, M,
+                                      hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        if (mi_out) {
+            double ld_xx = 0, ld_cov = 0;
+            ALGP_TRY(factor_resident(c, p(c->auxA), M, Mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld_xx));
+            ALGP_TRY(factor_resident(c, p(c->auxW), M, Mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld_cov));
+            *mi_out = 0.5 * (ld_xx - ld_cov);     // the k*CONST terms cancel (utils.py:314)
+        }
+        return ALGP_OK;
+    }
+
+    static int posterior_mean(algp_ctx* c, const int64_t* idx, int64_t M, void* mu_out) {
+        if (!c->factored) return fail(c, ALGP_ERR_STATE, "posterior_mean: call algp_factorize first");
+        if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "posterior_mean needs a coordinate pool");
+        if (M == 0) return ALGP_OK;
+        ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * M));
+        ALGP_TRY(ensure(c, c->auxD, sizeof(T) * M));
+        ALGP_HIP(hipMemcpyAsync(c->auxIdx.p, idx, sizeof(int64_t) * M, hipMemcpyHostToDevice, c->stream));
+        ALGP_TRY(kgemv_launch<T>(c, M, (const int64_t*)c->auxIdx.p, (const T*)c->Xs.p, c->hyp.DP, c->N,
+                                 (const int64_t*)c->Aidx.p, (const T*)c->alpha.p, c->hyp.kernel, (T)c->hyp.outputscale,
+                                 (T)c->ybar, p(c->auxD)));
+        ALGP_HIP(hipMemcpyAsync(mu_out, c->auxD.p, sizeof(T) * M, hipMemcpyDeviceToHost, c->stream));
+        return sync(c);
+    }
+
+    // ------------------------------------------------------------------ set entropies / inverse diagonals
+    static int build_set_matrix(algp_ctx* c, const int64_t* idx, int64_t m, const void* var, int64_t* mpad_out) {
+        const int64_t mpad = round_up(std::max<int64_t>(m, 1), NB);
+        *mpad_out = mpad;
+        ALGP_TRY(ensure(c, c->auxA, sizeof(T) * mpad * mpad));
+        ALGP_TRY(ensure(c, c->auxInv, sizeof(T) * mpad * NB));
+        ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * mpad));
+        ALGP_TRY(ensure(c, c->auxVar, sizeof(T) * mpad));
+        if (m > 0) ALGP_HIP(hipMemcpyAsync(c->auxIdx.p, idx, sizeof(int64_t) * m, hipMemcpyHostToDevice, c->stream));
+        if (var && m > 0)
+            ALGP_HIP(hipMemcpyAsync(c->auxVar.p, var, sizeof(T) * m, hipMemcpyHostToDevice, c->stream));
+        KmatSrc s = make_src(c);
+        return kmat_launch<T>(c, s, (const int64_t*)c->auxIdx.p, m, mpad, (const int64_t*)c->auxIdx.p, m, mpad,
+                              var ? (const T*)c->auxVar.p : nullptr, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->auxA),
+                              mpad);
+    }
+
+    static int set_entropy(algp_ctx* c, const int64_t* idx, int64_t m, const void* var, double* H) {
+        if (m == 0) { *H = 0.0; return ALGP_OK; }
+        int64_t mpad;
+        ALGP_TRY(build_set_matrix(c, idx, m, var, &mpad));
+        double ld = 0;
+        ALGP_TRY(factor_resident(c, p(c->auxA), m, mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
+        *H = (double)m * ENT_CONST + 0.5 * ld;
+        return ALGP_OK;
+    }
+
+    // diag(S^-1) = row sums of squares of L^-T (= I * L^-T through the blocked TRSM)
+    static int inverse_diag_resident(algp_ctx* c, int64_t m, int64_t mpad, void* diag_out) {
+        ALGP_TRY(ensure(c, c->auxW, sizeof(T) * mpad * mpad));
+        ALGP_TRY(ensure(c, c->auxD, sizeof(T) * mpad));
+        ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), mpad, mpad));
+        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), mpad, mpad, p(c->auxA), mpad, mpad, p(c->auxInv)));
+        ALGP_TRY(rows_reduce_launch<T>(c, p(c->auxW), m, mpad, mpad, (const T*)nullptr, p(c->auxD), (T*)nullptr));
+        ALGP_HIP(hipMemcpyAsync(diag_out, c->auxD.p, sizeof(T) * m, hipMemcpyDeviceToHost, c->stream));
+        return sync(c);
+    }
+
+    static int set_inverse_diag(algp_ctx* c, const int64_t* idx, int64_t m, const void* var, void* diag_out, double* H) {
+        if (m == 0) { if (H) *H = 0.0; return ALGP_OK; }
+        int64_t mpad;
+        ALGP_TRY(build_set_matrix(c, idx, m, var, &mpad));
+        double ld = 0;
+        ALGP_TRY(factor_resident(c, p(c->auxA), m, mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
+        if (H) *H = (double)m * ENT_CONST + 0.5 * ld;
+        return inverse_diag_resident(c, m, mpad, diag_out);
+    }
+
+    static int upload_padded(algp_ctx* c, DevBuf& b, const void* A, int64_t rows, int64_t cols, int64_t rpad,
+                             int64_t cpad) {
+        ALGP_TRY(ensure(c, b, sizeof(T) * rpad * cpad));
+        ALGP_HIP(hipMemsetAsync(b.p, 0, sizeof(T) * rpad * cpad, c->stream));
+        if (rows > 0 && cols > 0)
+            ALGP_HIP(hipMemcpy2DAsync(b.p, sizeof(T) * cpad, A, sizeof(T) * cols, sizeof(T) * cols, rows,
+                                      hipMemcpyHostToDevice, c->stream));
+        return ALGP_OK;
+    }
+
+    static int entropy_from_cov(algp_ctx* c, const void* cov, int64_t k, double* H, void* L_out, double* logdet) {
+        if (k == 0) { if (H) *H = 0.0; if (logdet) *logdet = 0.0; return ALGP_OK; }
+        const int64_t kpad = round_up(k, NB);
+        ALGP_TRY(upload_padded(c, c->auxA, cov, k, k, kpad, kpad));
+        ALGP_TRY(pad_identity_launch<T>(c, p(c->auxA), k, kpad, kpad));
+        ALGP_TRY(ensure(c, c->auxInv, sizeof(T) * kpad * NB));
+        double ld = 0;
+        ALGP_TRY(factor_resident(c, p(c->auxA), k, kpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
+        if (H) *H = (double)k * ENT_CONST + 0.5 * ld;
+        if (logdet) *logdet = ld;
+        if (L_out) {
+            ALGP_HIP(hipMemcpy2DAsync(L_out, sizeof(T) * k, c->auxA.p, sizeof(T) * kpad, sizeof(T) * k, k,
+                                      hipMemcpyDeviceToHost, c->stream));
+            ALGP_TRY(sync(c));
+            T* Lh = (T*)L_out;
+            for (int64_t i = 0; i < k; ++i)
+                for (int64_t j = i + 1; j < k; ++j) Lh[i * k + j] = (T)0;
+        }
+        return ALGP_OK;
+    }
+
+    static int gemm_host(algp_ctx* c, int64_t m, int64_t n, int64_t k, double alpha, const void* A, const void* B,
+                         double beta, const void* C, void* D) {
+        const int64_t mp = round_up(std::max<int64_t>(m, 1), NB), np = round_up(std::max<int64_t>(n, 1), NB),
+                      kp = round_up(std::max<int64_t>(k, 1), NB);
+        DevBuf a, b, cc;
+        int rc = upload_padded(c, a, A, m, k, mp, kp);
+        if (rc == ALGP_OK) rc = upload_padded(c, b, B, n, k, np, kp);
+        if (rc == ALGP_OK) rc = upload_padded(c, cc, (beta != 0.0 && C) ? C : nullptr, (beta != 0.0 && C) ? m : 0, n, mp, np);
+        if (rc == ALGP_OK)
+            rc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, mp, np, kp, (T)alpha, (const T*)a.p, kp, (const T*)b.p, kp,
+                                   (T)beta, (const T*)cc.p, np, (T*)cc.p, np, 0);
+        if (rc == ALGP_OK) {
+            hipError_t e = hipMemcpy2DAsync(D, sizeof(T) * n, cc.p, sizeof(T) * np, sizeof(T) * n, m,
+                                            hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(c, ALGP_ERR_HIP, hipGetErrorString(e));
+        }
+        hipStreamSynchronize(c->stream);
+        release(c, a); release(c, b); release(c, cc);
+        return rc;
+    }
+
+    static int trsm_host(algp_ctx* c, const void* L, int64_t n, const void* B, int64_t m, void* X) {
+        const int64_t np = round_up(std::max<int64_t>(n, 1), NB), mp = round_up(std::max<int64_t>(m, 1), NB);
+        DevBuf l, b, inv;
+        int rc = upload_padded(c, l, L, n, n, np, np);
+        if (rc == ALGP_OK) rc = pad_identity_launch<T>(c, (T*)l.p, n, np, np);
+        if (rc == ALGP_OK) rc = upload_padded(c, b, B, m, n, mp, np);
+        if (rc == ALGP_OK) rc = ensure(c, inv, sizeof(T) * np * NB);
+        for (int64_t kb = 0; rc == ALGP_OK && kb < np / NB; ++kb)
+            rc = trinv_diag_launch<T>(c, (const T*)l.p + kb * NB * np + kb * NB, np, (T*)inv.p + kb * NB * NB);
+        if (rc == ALGP_OK) rc = trsm_blocked<T>(c, ALGP_PROF_GEMM_OTHER, (T*)b.p, mp, np, (const T*)l.p, np, np, (const T*)inv.p);
+        if (rc == ALGP_OK) {
+            hipError_t e = hipMemcpy2DAsync(X, sizeof(T) * n, b.p, sizeof(T) * np, sizeof(T) * n, m,
+                                            hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(c, ALGP_ERR_HIP, hipGetErrorString(e));
+        }
+        hipStreamSynchronize(c->stream);
+        release(c, l); release(c, b); release(c, inv);
+        return rc;
+    }
+
+    // ------------------------------------------------------------------ greedy
+    // MI criterion extra terms per local candidate: H(A) + H(Abar \ i) - H(all_i)   (agent.py:331-339)
+    static int mi_extra(algp_ctx* c, double ss, double sm, std::vector<double>& extra) {
+        const int64_t n = c->n_pool, M = c->M;
+        const double vf = 1.0 / (1.0 / ss + 1.0 / sm), delta = vf - sm;
+        // current state: train set (with its noise) + committed picks
+        std::vector<char> sampled(n, 0);
+        std::vector<double> noise(n, 0.0);
+        std::vector<T> trvar(c->Npad);
+        ALGP_HIP(hipMemcpyAsync(trvar.data(), c->varA.p, sizeof(T) * c->Npad, hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        for (int64_t a = 0; a < c->N; ++a) { sampled[c->train_idx[a]] = 1; noise[c->train_idx[a]] = (double)trvar[a]; }
+        for (auto& pk : c->picks) {
+            noise[pk.pool_idx] = sampled[pk.pool_idx] ? vf : ss;
+            sampled[pk.pool_idx] = 1;
+        }
+        std::vector<int64_t> A, Abar, all(n);
+        std::vector<T> vA, vall(n);
+        std::vector<int64_t> pos_bar(n, -1);
+        for (int64_t i = 0; i < n; ++i) {
+            all[i] = i;
+            vall[i] = (T)noise[i];
+            if (sampled[i]) { A.push_back(i); vA.push_back((T)noise[i]); }
+            else { pos_bar[i] = (int64_t)Abar.size(); Abar.push_back(i); }
+        }
+        double H_A = 0, H_bar = 0, H_all = 0;
+        std::vector<T> inv_bar(std::max<size_t>(Abar.size(), 1)), inv_all(n);
+        ALGP_TRY(set_entropy(c, A.data(), (int64_t)A.size(), vA.data(), &H_A));
+        // C_AbarAbar carries no measurement noise (agent.py:331)
+        ALGP_TRY(set_inverse_diag(c, Abar.data(), (int64_t)Abar.size(), nullptr, inv_bar.data(), &H_bar));
+        ALGP_TRY(set_inverse_diag(c, all.data(), n, vall.data(), inv_all.data(), &H_all));
+        extra.assign(M, 0.0);
+        for (int64_t j = 0; j < M; ++j) {
+            const int64_t i = c->cand_idx[j];
+            if (sampled[i]) {
+                extra[j] = H_A + H_bar - (H_all + 0.5 * log1p(delta * (double)inv_all[i]));
+            } else {
+                extra[j] = H_A + (H_bar - ENT_CONST + 0.5 * log((double)inv_bar[pos_bar[i]])) -
+                           (H_all + 0.5 * log1p(ss * (double)inv_all[i]));
+            }
+        }
+        return ALGP_OK;
+    }
+
+    static int scores(algp_ctx* c, int criterion, double static_std, double mobile_std, void* out, int out_is_device) {
+        if (!c->solved) return fail(c, ALGP_ERR_STATE, "scores: call algp_solve_candidates first");
+        if (!c->prior_noise) return fail(c, ALGP_ERR_STATE, "scores: candidates were set with predictive semantics");
+        const double ss = static_std * static_std, sm = mobile_std * mobile_std;
+        const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
+        const double* extra_dev = nullptr;
+        if (criterion == ALGP_CRIT_MUTUAL_INFORMATION) {
+            std::vector<double> extra;
+            ALGP_TRY(mi_extra(c, ss, sm, extra));
+            ALGP_TRY(ensure(c, c->hostStage, sizeof(double) * c->Mpad));
+            ALGP_HIP(hipMemcpyAsync(c->hostStage.p, extra.data(), sizeof(double) * c->M, hipMemcpyHostToDevice, c->stream));
+            ALGP_TRY(sync(c));
+            extra_dev = (const double*)c->hostStage.p;
+        } else if (criterion != ALGP_CRIT_ENTROPY) {
+            return fail(c, ALGP_ERR_BAD_ARG, "unknown criterion");
+        }
+        double* dst = out_is_device ? (double*)out : (double*)c->scores.p;
+        ALGP_TRY(score_launch<T>(c, c->M, (const int*)c->ckind.p, (const unsigned char*)c->alive.p, (const T*)c->dstat.p,
+                                 ss, delta, extra_dev, dst));
+        if (out_is_device) {
+            ALGP_HIP(hipMemcpyAsync(c->scores.p, dst, sizeof(double) * c->M, hipMemcpyDeviceToDevice, c->stream));
+        } else if (out) {
+            ALGP_HIP(hipMemcpyAsync(out, c->scores.p, sizeof(double) * c->M, hipMemcpyDeviceToHost, c->stream));
+        }
+        return sync(c);
+    }
+
+    static int argmax(algp_ctx* c, int64_t* local_pos, int64_t* pool_idx, double* value) {
+        if (!c->solved) return fail(c, ALGP_ERR_STATE, "argmax: no scores");
+        if (c->M == 0) return fail(c, ALGP_ERR_BAD_ARG, "argmax: empty candidate set");
+        double* sc = (double*)c->scal.p;
+        ALGP_TRY(argmax_launch(c, (const double*)c->scores.p, c->M, sc + SC_AMAXV, (int64_t*)(sc + SC_AMAXI)));
+        double host[2];
+        ALGP_HIP(hipMemcpyAsync(host, sc + SC_AMAXV, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        int64_t pos;
+        memcpy(&pos, &host[1], sizeof(int64_t));
+        if (local_pos) *local_pos = pos;
+        if (pool_idx) *pool_idx = pos >= 0 ? c->cand_idx[pos] : -1;
+        if (value) *value = host[0];
+        return ALGP_OK;
+    }
+
+    // row of V^T for a pool index that is not a local candidate (sharded scoring: the global winner
+    // lives on another rank).  Forward solve + the entries appended by earlier picks.
+    static int remote_row(algp_ctx* c, int64_t pool_idx, int in_train, double* dc_out) {
+        const int64_t N = c->N, Npad = c->Npad, ldv = c->ldv;
+        T* l = p(c->lrow);
+        ALGP_HIP(hipMemsetAsync(l, 0, sizeof(T) * ldv, c->stream));
+        ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * 8));
+        int unit_host = in_train ? (int)c->pos_in_train[pool_idx] : -1;
+        int* unit_dev = (int*)((int64_t*)c->auxIdx.p + 1);
+        ALGP_HIP(hipMemcpyAsync(c->auxIdx.p, &pool_idx, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemcpyAsync(unit_dev, &unit_host, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        KmatSrc s = make_src(c);
+        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->auxIdx.p, 1, 1, (const int64_t*)c->Aidx.p, N, Npad, nullptr, 0,
+                                unit_dev, 0, l, ldv));
+        ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, Npad, p(c->invD), l));
+        // host finishes the (at most MAX_APPEND) appended entries: tiny dot products on downloaded rows
+        std::vector<T> lh(ldv);
+        ALGP_HIP(hipMemcpyAsync(lh.data(), l, sizeof(T) * ldv, hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        std::vector<T> prev(ldv);
+        for (size_t q = 0; q < c->picks.size(); ++q) {
+            const int64_t nc = Npad + (int64_t)q;
+            ALGP_HIP(hipMemcpyAsync(prev.data(), p(c->prevrows) + (int64_t)q * ldv, sizeof(T) * nc, hipMemcpyDeviceToHost, c->stream));
+            ALGP_TRY(sync(c));
+            double t = 0;
+            for (int64_t r = 0; r < nc; ++r) t += (double)lh[r] * (double)prev[r];
+            double bp = 0;
+            if (!c->picks[q].in_train && !in_train) {
+                T v;
+                ALGP_TRY(pool_entry(c, c->picks[q].pool_idx, pool_idx, &v));
+                bp = (double)v;
+            }
+            lh[nc] = (T)((bp - t) * c->picks[q].scale);
+        }
+        ALGP_HIP(hipMemcpyAsync(l, lh.data(), sizeof(T) * ldv, hipMemcpyHostToDevice, c->stream));
+        ALGP_TRY(sync(c));
+        double ssq = 0;
+        for (int64_t r = 0; r < c->ncols; ++r) ssq += (double)lh[r] * (double)lh[r];
+        if (in_train) {
+            *dc_out = ssq;
+        } else {
+            T prior;
+            ALGP_TRY(pool_entry(c, pool_idx, pool_idx, &prior));
+            *dc_out = (double)prior - ssq;
+        }
+        return ALGP_OK;
+    }
+
+    // C(i, j) of the pool (with sigma_n^2 when i == j), one value, through the device kernel
+    static int pool_entry(algp_ctx* c, int64_t i, int64_t j, T* out) {
+        ALGP_TRY(ensure(c, c->auxVar, sizeof(T) * 8 + 2 * sizeof(int64_t) + 64));
+        int64_t* ij = (int64_t*)((char*)c->auxVar.p + 64);
+        int64_t host[2] = {i, j};
+        ALGP_HIP(hipMemcpyAsync(ij, host, sizeof(host), hipMemcpyHostToDevice, c->stream));
+        KmatSrc s = make_src(c);
+        ALGP_TRY(kmat_launch<T>(c, s, ij, 1, 1, ij + 1, 1, 16 / sizeof(T), nullptr, c->pool_is_cov ? 0 : 1, nullptr, 0,
+                                (T*)c->auxVar.p, 16 / sizeof(T)));
+        ALGP_HIP(hipMemcpyAsync(out, c->auxVar.p, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        return sync(c);
+    }
+
+    static int commit_pick(algp_ctx* c, int64_t pool_idx, double static_std, double mobile_std) {
+        if (!c->solved) return fail(c, ALGP_ERR_STATE, "commit_pick: call algp_solve_candidates first");
+        if (pool_idx < 0 || pool_idx >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: index outside the pool");
+        if ((int64_t)c->picks.size() >= MAX_APPEND) return fail(c, ALGP_ERR_STATE, "commit_pick: append capacity exhausted; re-factorize");
+        for (auto& pk : c->picks)
+            if (pk.pool_idx == pool_idx) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: site already static-sampled");
+        const double ss = static_std * static_std, sm = mobile_std * mobile_std;
+        const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
+        const int in_train = c->pos_in_train[pool_idx] >= 0 ? 1 : 0;
+        const int64_t local = c->cand_pos[pool_idx];
+        const int64_t ldv = c->ldv, ncols = c->ncols;
+        double dc = 0;
+        if (local >= 0) {
+            ALGP_HIP(hipMemsetAsync(c->lrow.p, 0, sizeof(T) * ldv, c->stream));
+            ALGP_HIP(hipMemcpyAsync(c->lrow.p, p(c->Vt) + local * ldv, sizeof(T) * ncols, hipMemcpyDeviceToDevice, c->stream));
+            T dch;
+            ALGP_HIP(hipMemcpyAsync(&dch, p(c->dstat) + local, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+            ALGP_TRY(sync(c));
+            dc = (double)dch;
+        } else {
+            ALGP_TRY(remote_row(c, pool_idx, in_train, &dc));
+        }
+        double scale;
+        if (in_train) {
+            const double gamma = delta / (1.0 + delta * dc);
+            scale = sqrt(-gamma);
+        } else {
+            scale = 1.0 / sqrt(dc + ss);
+        }
+        if (!(scale == scale) || isinf(scale))
+            return fail(c, ALGP_ERR_NOT_PD, "commit_pick: posterior variance of the pick is not positive");
+        T* t = p(c->tvec);
+        ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), c->M, ldv, ncols, p(c->lrow), (T*)nullptr, t));
+        ALGP_TRY(pick_update_launch<T>(c, c->M, (const int*)c->ckind.p, (const int64_t*)c->Cidx.p, (const T*)c->Xs.p,
+                                       c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, c->hyp.DP, pool_idx,
+                                       in_train, c->hyp.kernel, (T)c->hyp.outputscale, (T)c->hyp.noise, t, (T)scale,
+                                       p(c->dstat), p(c->Vt), ldv, ncols));
+        ALGP_HIP(hipMemcpyAsync(p(c->prevrows) + (int64_t)c->picks.size() * ldv, c->lrow.p, sizeof(T) * ldv,
+                                hipMemcpyDeviceToDevice, c->stream));
+        if (local >= 0) ALGP_HIP(hipMemsetAsync((unsigned char*)c->alive.p + local, 0, 1, c->stream));
+        ALGP_TRY(sync(c));
+        PickRec pr;
+        pr.pool_idx = pool_idx;
+        pr.in_train = in_train;
+        pr.scale = scale;
+        c->picks.push_back(pr);
+        c->ncols = ncols + 1;
+        return ALGP_OK;
+    }
+
+    static int greedy(algp_ctx* c, int criterion, double static_std, double mobile_std, int k, const int64_t* forced,
+                      int64_t* picks_out, double* ut_out) {
+        for (int pck = 0; pck < k; ++pck) {
+            ALGP_TRY(scores(c, criterion, static_std, mobile_std, ut_out ? ut_out + (int64_t)pck * c->M : nullptr, 0));
+            int64_t pool_idx;
+            if (forced) {
+                pool_idx = forced[pck];
+            } else {
+                ALGP_TRY(argmax(c, nullptr, &pool_idx, nullptr));
+            }
+            if (picks_out) picks_out[pck] = pool_idx;
+            ALGP_TRY(commit_pick(c, pool_idx, static_std, mobile_std));
+        }
+        return ALGP_OK;
+    }
+
+    static int get_alpha(algp_ctx* c, void* out) {
+        if (!c->factored) return fail(c, ALGP_ERR_STATE, "get_alpha: call algp_factorize first");
+        ALGP_HIP(hipMemcpyAsync(out, c->alpha.p, sizeof(T) * c->N, hipMemcpyDeviceToHost, c->stream));
+        return sync(c);
+    }
+    static int get_factor(algp_ctx* c, void* out) {
+        if (!c->factored) return fail(c, ALGP_ERR_STATE, "get_factor: call algp_factorize first");
+        const int64_t N = c->N;
+        ALGP_HIP(hipMemcpy2DAsync(out, sizeof(T) * N, c->L.p, sizeof(T) * c->Npad, sizeof(T) * N, N, hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        T* Lh = (T*)out;
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = i + 1; j < N; ++j) Lh[i * N + j] = (T)0;
+        return ALGP_OK;
+    }
+    static int selftest(algp_ctx* c, int* mism) {
+        double* sc = (double*)c->scal.p;
+        int* d = (int*)(sc + SC_PROBE);
+        ALGP_HIP(hipMemsetAsync(d, 0, sizeof(double), c->stream));
+        ALGP_TRY(test_mfma_launch<double>(c, d));
+        ALGP_TRY(test_mfma_launch<float>(c, d));
+        ALGP_HIP(hipMemcpyAsync(mism, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        return sync(c);
+    }
+};
+
+}  // namespace
+
+#define DISPATCH(c, call) ((c)->dtype == ALGP_F64 ? Impl<double>::call : Impl<float>::call)
+#define CHECK_CTX(c) do { if (!(c)) return ALGP_ERR_BAD_ARG; (c)->err.clear(); hipSetDevice((c)->device); } while (0)
+#define NEED_HYPERS(c) do { if (!(c)->hyp.set) return fail(c, ALGP_ERR_STATE, "call algp_set_hypers first"); } while (0)
+#define FINISH(c, expr) do { int rc__ = (expr); if ((c)->prof_on) prof_collect(c); return rc__; } while (0)
+
+extern "C" {
+
+int algp_version(void) { return 100; }
+
+int algp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int algp_create(int device_id, int dtype, algp_ctx** out) {
+    if (!out || (dtype != ALGP_F32 && dtype != ALGP_F64)) return ALGP_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ALGP_ERR_NO_DEVICE; }
+    if (device_id < 0 || device_id >= n) return ALGP_ERR_BAD_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return ALGP_ERR_HIP;
+    algp_ctx* c = new algp_ctx();
+    c->device = device_id;
+    c->dtype = dtype;
+    c->es = dtype == ALGP_F64 ? 8 : 4;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ALGP_ERR_HIP; }
+    if (ensure(c, c->scal, sizeof(double) * SC_COUNT) != ALGP_OK) { hipStreamDestroy(c->stream); delete c; return ALGP_ERR_OOM; }
+    hipMemsetAsync(c->scal.p, 0, sizeof(double) * SC_COUNT, c->stream);
+    hipStreamSynchronize(c->stream);
+    *out = c;
+    return ALGP_OK;
+}
+
+void algp_destroy(algp_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
+                      &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
+                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->auxVar, &c->auxD, &c->hostStage};
+    for (DevBuf* b : bufs) release(c, *b);
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* algp_last_error(const algp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int64_t algp_last_pivot(const algp_ctx* c) { return c ? c->pivot : 0; }
+int algp_dtype(const algp_ctx* c) { return c ? c->dtype : -1; }
+
+int algp_set_hypers(algp_ctx* c, int kernel, int D, const double* log_ls, double log_os, double log_noise) {
+    CHECK_CTX(c);
+    if (D < 1 || D > MAXD || !log_ls) return fail(c, ALGP_ERR_BAD_ARG, "set_hypers: 1 <= D <= 8 required");
+    if (kernel != ALGP_KERNEL_RBF && kernel != ALGP_KERNEL_MATERN15) return fail(c, ALGP_ERR_BAD_ARG, "set_hypers: unknown kernel");
+    if (c->hyp.set && c->hyp.D != D && c->n_pool > 0 && !c->pool_is_cov)
+        return fail(c, ALGP_ERR_STATE, "set_hypers: input dimension changed while a pool is resident");
+    c->hyp.kernel = kernel;
+    c->hyp.D = D;
+    c->hyp.DP = D <= 2 ? 2 : (D <= 4 ? 4 : 8);
+    for (int d = 0; d < MAXD; ++d) c->hyp.inv_ls[d] = d < D ? exp(-log_ls[d]) : 0.0;
+    c->hyp.outputscale = exp(log_os);
+    c->hyp.noise = exp(log_noise);
+    c->hyp.set = true;
+    c->factored = false;
+    c->solved = false;
+    FINISH(c, DISPATCH(c, rescale_pool(c)));
+}
+
+int algp_kernel_matrix(algp_ctx* c, const void* x1, int64_t n1, const void* x2, int64_t n2, const void* diag_add,
+                       int add_lik, void* out) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (!x1 || n1 < 0 || n2 < 0 || !out) return fail(c, ALGP_ERR_BAD_ARG, "kernel_matrix: bad arguments");
+    FINISH(c, DISPATCH(c, kernel_matrix(c, x1, n1, x2, n2, diag_add, add_lik, out)));
+}
+
+int algp_set_pool(algp_ctx* c, const void* x, int64_t n) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (!x || n <= 0) return fail(c, ALGP_ERR_BAD_ARG, "set_pool: bad arguments");
+    c->factored = c->solved = false;
+    c->pos_in_train.clear();
+    c->N = 0;
+    FINISH(c, DISPATCH(c, set_pool(c, x, n)));
+}
+
+int algp_set_pool_cov(algp_ctx* c, const void* cov, int64_t n) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (!cov || n <= 0) return fail(c, ALGP_ERR_BAD_ARG, "set_pool_cov: bad arguments");
+    c->factored = c->solved = false;
+    c->pos_in_train.clear();
+    c->N = 0;
+    FINISH(c, DISPATCH(c, set_pool_cov(c, cov, n)));
+}
+
+int algp_set_train(algp_ctx* c, const int64_t* idx, int64_t N, const void* y, const void* var) {
+    CHECK_CTX(c);
+    if (c->n_pool <= 0) return fail(c, ALGP_ERR_STATE, "set_train: set a pool first");
+    if (N < 0 || (N > 0 && (!idx || !y))) return fail(c, ALGP_ERR_BAD_ARG, "set_train: bad arguments");
+    std::vector<char> seen(c->n_pool, 0);
+    for (int64_t i = 0; i < N; ++i) {
+        if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "set_train: index outside the pool");
+        if (seen[idx[i]]) return fail(c, ALGP_ERR_BAD_ARG, "set_train: duplicate pool index");
+        seen[idx[i]] = 1;
+    }
+    FINISH(c, DISPATCH(c, set_train(c, idx, N, y, var)));
+}
+
+int algp_factorize(algp_ctx* c) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (c->n_pool <= 0) return fail(c, ALGP_ERR_STATE, "factorize: set a pool first");
+    // an empty train set is legal (greedy from an empty field: agent.py:308 with a 0 x 0 slogdet = 0),
+    // but it has to be declared through algp_set_train(ctx, NULL, 0, NULL, NULL)
+    if (!c->y0.p || (int64_t)c->pos_in_train.size() != c->n_pool)
+        return fail(c, ALGP_ERR_STATE, "factorize: call algp_set_train first");
+    FINISH(c, DISPATCH(c, factorize(c)));
+}
+
+int algp_get_logdet(algp_ctx* c, double* logdet) {
+    CHECK_CTX(c);
+    if (!c->factored || !logdet) return fail(c, ALGP_ERR_STATE, "get_logdet: call algp_factorize first");
+    *logdet = c->logdet;
+    return ALGP_OK;
+}
+int algp_get_entropy(algp_ctx* c, double* H) {
+    CHECK_CTX(c);
+    if (!c->factored || !H) return fail(c, ALGP_ERR_STATE, "get_entropy: call algp_factorize first");
+    *H = (double)c->N * ENT_CONST + 0.5 * c->logdet;
+    return ALGP_OK;
+}
+int algp_get_mll(algp_ctx* c, double* mll) {
+    CHECK_CTX(c);
+    if (!c->factored || !mll) return fail(c, ALGP_ERR_STATE, "get_mll: call algp_factorize first");
+    *mll = -0.5 * c->yalpha - 0.5 * c->logdet - 0.5 * (double)c->N * 1.8378770664093453;
+    return ALGP_OK;
+}
+int algp_get_alpha(algp_ctx* c, void* out) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_alpha(c, out))); }
+int algp_get_factor(algp_ctx* c, void* out) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_factor(c, out))); }
+
+int algp_set_candidates(algp_ctx* c, const int64_t* idx, int64_t M, int prior_noise, const void* extra) {
+    CHECK_CTX(c);
+    if (c->n_pool <= 0) return fail(c, ALGP_ERR_STATE, "set_candidates: set a pool first");
+    if (M < 0 || (M > 0 && !idx)) return fail(c, ALGP_ERR_BAD_ARG, "set_candidates: bad arguments");
+    for (int64_t i = 0; i < M; ++i)
+        if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "set_candidates: index outside the pool");
+    FINISH(c, DISPATCH(c, set_candidates(c, idx, M, prior_noise, extra)));
+}
+int algp_solve_candidates(algp_ctx* c) { CHECK_CTX(c); FINISH(c, DISPATCH(c, solve_candidates(c))); }
+int algp_get_posterior(algp_ctx* c, void* mu, void* var) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_posterior(c, mu, var))); }
+int algp_get_posterior_cov(algp_ctx* c, void* cov, double* mi) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_posterior_cov(c, cov, mi))); }
+int algp_posterior_mean(algp_ctx* c, const int64_t* idx, int64_t M, void* mu) {
+    CHECK_CTX(c);
+    if (M < 0 || (M > 0 && (!idx || !mu))) return fail(c, ALGP_ERR_BAD_ARG, "posterior_mean: bad arguments");
+    for (int64_t i = 0; i < M; ++i)
+        if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "posterior_mean: index outside the pool");
+    FINISH(c, DISPATCH(c, posterior_mean(c, idx, M, mu)));
+}
+
+int algp_scores(algp_ctx* c, int criterion, double static_std, double mobile_std, void* out, int out_is_device) {
+    CHECK_CTX(c);
+    FINISH(c, DISPATCH(c, scores(c, criterion, static_std, mobile_std, out, out_is_device)));
+}
+int algp_argmax(algp_ctx* c, int64_t* local_pos, int64_t* pool_idx, double* value) {
+    CHECK_CTX(c);
+    FINISH(c, DISPATCH(c, argmax(c, local_pos, pool_idx, value)));
+}
+int algp_commit_pick(algp_ctx* c, int64_t pool_idx, double static_std, double mobile_std) {
+    CHECK_CTX(c);
+    FINISH(c, DISPATCH(c, commit_pick(c, pool_idx, static_std, mobile_std)));
+}
+int algp_greedy(algp_ctx* c, int criterion, double static_std, double mobile_std, int k, const int64_t* forced,
+                int64_t* picks_out, double* ut_out) {
+    CHECK_CTX(c);
+    if (k < 0 || k > MAX_APPEND) return fail(c, ALGP_ERR_BAD_ARG, "greedy: 0 <= k <= 128");
+    FINISH(c, DISPATCH(c, greedy(c, criterion, static_std, mobile_std, k, forced, picks_out, ut_out)));
+}
+
+int algp_entropy_from_cov(algp_ctx* c, const void* cov, int64_t k, double* H) {
+    CHECK_CTX(c);
+    if (k < 0 || !H || (k > 0 && !cov)) return fail(c, ALGP_ERR_BAD_ARG, "entropy_from_cov: bad arguments");
+    FINISH(c, DISPATCH(c, entropy_from_cov(c, cov, k, H, nullptr, nullptr)));
+}
+int algp_set_entropy(algp_ctx* c, const int64_t* idx, int64_t m, const void* var, double* H) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (m < 0 || !H || (m > 0 && !idx)) return fail(c, ALGP_ERR_BAD_ARG, "set_entropy: bad arguments");
+    for (int64_t i = 0; i < m; ++i)
+        if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "set_entropy: index outside the pool");
+    FINISH(c, DISPATCH(c, set_entropy(c, idx, m, var, H)));
+}
+int algp_set_inverse_diag(algp_ctx* c, const int64_t* idx, int64_t m, const void* var, void* diag_out, double* H) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (m < 0 || (m > 0 && (!idx || !diag_out))) return fail(c, ALGP_ERR_BAD_ARG, "set_inverse_diag: bad arguments");
+    for (int64_t i = 0; i < m; ++i)
+        if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "set_inverse_diag: index outside the pool");
+    FINISH(c, DISPATCH(c, set_inverse_diag(c, idx, m, var, diag_out, H)));
+}
+
+int algp_cholesky(algp_ctx* c, const void* A, int64_t n, void* L_out, double* logdet) {
+    CHECK_CTX(c);
+    if (n < 0 || (n > 0 && !A)) return fail(c, ALGP_ERR_BAD_ARG, "cholesky: bad arguments");
+    FINISH(c, DISPATCH(c, entropy_from_cov(c, A, n, nullptr, L_out, logdet)));
+}
+int algp_gemm_nt(algp_ctx* c, int64_t m, int64_t n, int64_t k, double alpha, const void* A, const void* B, double beta,
+                 const void* C, void* D) {
+    CHECK_CTX(c);
+    if (m <= 0 || n <= 0 || k <= 0 || !A || !B || !D) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: bad arguments");
+    FINISH(c, DISPATCH(c, gemm_host(c, m, n, k, alpha, A, B, beta, C, D)));
+}
+int algp_trsm_right_lt(algp_ctx* c, const void* L, int64_t n, const void* B, int64_t m, void* X) {
+    CHECK_CTX(c);
+    if (m <= 0 || n <= 0 || !L || !B || !X) return fail(c, ALGP_ERR_BAD_ARG, "trsm: bad arguments");
+    FINISH(c, DISPATCH(c, trsm_host(c, L, n, B, m, X)));
+}
+int algp_selftest_mfma(algp_ctx* c, int* mismatches) {
+    CHECK_CTX(c);
+    if (!mismatches) return fail(c, ALGP_ERR_BAD_ARG, "selftest: bad arguments");
+    return Impl<double>::selftest(c, mismatches);
+}
+
+int algp_sync(algp_ctx* c) { CHECK_CTX(c); return sync(c); }
+int64_t algp_device_bytes(const algp_ctx* c) { return c ? c->dev_bytes : 0; }
+
+int algp_prof_enable(algp_ctx* c, int on) {
+    CHECK_CTX(c);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    c->prof_on = on != 0;
+    return ALGP_OK;
+}
+int algp_prof_reset(algp_ctx* c) {
+    CHECK_CTX(c);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (int i = 0; i < ALGP_PROF_COUNT; ++i) c->prof[i] = ProfSlot();
+    return ALGP_OK;
+}
+int algp_prof_get(algp_ctx* c, int klass, double* ms, double* flops, double* bytes, int64_t* launches) {
+    CHECK_CTX(c);
+    if (klass < 0 || klass >= ALGP_PROF_COUNT) return fail(c, ALGP_ERR_BAD_ARG, "prof_get: unknown class");
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    if (ms) *ms = c->prof[klass].ms;
+    if (flops) *flops = c->prof[klass].flops;
+    if (bytes) *bytes = c->prof[klass].bytes;
+    if (launches) *launches = c->prof[klass].launches;
+    return ALGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// Internal declarations shared by the HIP translation units of libalgp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/algp_hip.h"
+
+namespace algp {
+
+constexpr int NB = 128;          // factor block / GEMM tile edge; every device matrix is padded to it
+constexpr int MAXD = 8;          // coordinates are stored scaled by 1/lengthscale and zero-padded to DP
+constexpr int MAX_APPEND = 128;  // rows a greedy run may append to V^T (ldv = Npad + MAX_APPEND)
+constexpr double ENT_CONST = 1.4189385332046727;  // 1/2 log(2 pi e)  (reference utils.py:10)
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfSlot {
+    double ms = 0, flops = 0, bytes = 0;
+    int64_t launches = 0;
+};
+
+struct PendingEvent {
+    hipEvent_t a, b;
+    int klass;
+};
+
+struct Hypers {
+    int kernel = ALGP_KERNEL_RBF;
+    int D = 0, DP = 2;
+    double inv_ls[MAXD] = {0};
+    double outputscale = 1.0, noise = 1.0;
+    bool set = false;
+};
+
+struct PickRec {           // one committed greedy pick (needed to extend a remote winner's row)
+    int64_t pool_idx;
+    int in_train;          // winner was a mobile-sampled train site (rank-1 noise change)
+    double scale;          // 1/lambda (append) or sqrt(-gamma) (noise change)
+};
+
+}  // namespace algp
+
+struct algp_ctx {
+    int device = 0;
+    int dtype = ALGP_F64;
+    size_t es = 8;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int64_t pivot = 0;
+    algp::Hypers hyp;
+
+    // pool
+    int64_t n_pool = 0;
+    bool pool_is_cov = false;
+    algp::DevBuf Xs;        // n x DP scaled, zero padded coordinates
+    algp::DevBuf Xraw;      // n x D raw coordinates (kept to rescale on a hyper change)
+    algp::DevBuf Cp;        // n x n explicit covariance (pool_is_cov)
+    std::vector<int64_t> pos_in_train;   // host: pool index -> position in train set or -1
+
+    // train set / factor
+    int64_t N = 0, Npad = 0;
+    std::vector<int64_t> train_idx;
+    algp::DevBuf Aidx, yA, varA, y0, L, invD, z, alpha, scal;   // scal: device doubles (logdet, info...)
+    double ybar = 0, logdet = 0, yalpha = 0;
+    bool factored = false;
+
+    // candidates
+    int64_t M = 0, Mpad = 0, ldv = 0;
+    int64_t ncols = 0;       // active columns of V^T (Npad + appended)
+    int prior_noise = 1;
+    std::vector<int64_t> cand_idx;
+    std::vector<int64_t> cand_pos;       // host: pool index -> local candidate position or -1
+    algp::DevBuf Cidx, ckind, cextra, Vt, dstat, mu, alive, scores, lrow, tvec, amax;
+    std::vector<algp::PickRec> picks;
+    algp::DevBuf prevrows;   // MAX_APPEND x ldv: the l-rows of committed picks
+    bool solved = false;
+
+    // scratch for auxiliary factorizations (entropy_from_cov, set entropies, MI terms, posterior cov)
+    algp::DevBuf auxA, auxInv, auxW, auxIdx, auxVar, auxD, hostStage;
+
+    // profiling
+    bool prof_on = false;
+    algp::ProfSlot prof[ALGP_PROF_COUNT];
+    std::vector<algp::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    int64_t dev_bytes = 0;
+};
+
+namespace algp {
+
+int fail(algp_ctx* c, int code, const std::string& msg);
+int ensure(algp_ctx* c, DevBuf& b, size_t bytes);
+void prof_begin(algp_ctx* c, int klass, double flops, double bytes);
+void prof_end(algp_ctx* c);
+void prof_collect(algp_ctx* c);
+
+#define ALGP_HIP(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return algp::fail(c, ALGP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define ALGP_TRY(call)          \
+    do {                        \
+        int r_ = (call);        \
+        if (r_ != ALGP_OK) return r_; \
+    } while (0)
+
+struct ProfScope {
+    algp_ctx* c;
+    ProfScope(algp_ctx* c_, int klass, double flops, double bytes) : c(c_) { prof_begin(c, klass, flops, bytes); }
+    ~ProfScope() { prof_end(c); }
+};
+
+// ---- typed kernels (definitions in the .hip files; explicit instantiation for float, double) ----
+struct KmatSrc {
+    // generator of C(pi, pj): coordinates (scaled, padded) or explicit pool covariance
+    const void* Xs;      // n x DP
+    const void* Cp;      // n x n or null
+    int64_t n_pool;
+    int DP;
+    int kernel;
+    double outputscale;
+    double noise;        // sigma_n^2 added when pool indices coincide (coords mode only)
+};
+
+// out[r][c] for r<rows_pad, c<cols_pad (ld = ldo):
+//   r<rows && c<cols : value(ridx[r], cidx[c])  [+ diag terms when the pool indices coincide]
+//   unit != null && unit[r] >= 0 : (c == unit[r]) ? 1 : 0      (e_j rows of B^T)
+//   padding: identity_pad ? (r==c) : 0
+template <typename T>
+int kmat_launch(algp_ctx* c, const KmatSrc& s, const int64_t* ridx, int64_t rows, int64_t rows_pad,
+                const int64_t* cidx, int64_t cols, int64_t cols_pad, const T* diag_add,
+                int add_noise_on_equal, const int* unit, int identity_pad, T* out, int64_t ldo);
+
+// plain (non-pool) kernel matrix between two scaled coordinate arrays, for algp_kernel_matrix
+template <typename T>
+int kmat_xy_launch(algp_ctx* c, const T* xs1, int64_t n1, const T* xs2, int64_t n2, int symmetric,
+                   const T* diag_add, double add_noise, T* out, int64_t ldo);
+template <typename T>
+int scale_coords_launch(algp_ctx* c, const T* x, int64_t n, T* xs);
+
+template <typename T>
+int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+                   int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
+                   int64_t ldd, int lower_only);
+
+// factor the NB x NB diagonal block at A (ld = lda) in place, write its inverse (NB x NB, ld NB),
+// add sum(log pivot) to *logdet_acc, record first bad pivot (block_row0 + j + 1) in *info (atomicMin style).
+template <typename T>
+int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet_acc, int* info,
+                      int64_t block_row0);
+
+// blocked right-looking Cholesky of the npad x npad matrix A (ld), inverse diagonal blocks to invD
+template <typename T>
+int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc,
+                     int* info);
+// X (mpad x npad, ld ldx) <- X * L^-T, in place
+template <typename T>
+int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
+                 int64_t ldl, const T* invD);
+// b <- L^-1 b (forward) and b <- L^-T b (backward) for one vector of length npad
+template <typename T>
+int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b);
+template <typename T>
+int trsv_backward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b);
+
+// row reductions over V^T: ss[j] = sum_r V[j][r]^2 (if ss), dot[j] = sum_r V[j][r]*w[r] (if w)
+template <typename T>
+int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t ncols, const T* w,
+                       T* ss, T* dot);
+
+template <typename T>
+int test_mfma_launch(algp_ctx* c, int* mismatches_dev);
+
+}  // namespace algp

@@ -1,0 +1,254 @@
+// gemm.hip -- D = alpha * A * B^T + beta * C on the gfx950 matrix cores, fp64 and fp32.
+//
+// This one kernel carries every O(n^3) term of the path: the Cholesky panel solve and trailing
+// (SYRK) update, the candidate solve V^T = B^T L^-T, and the posterior covariance V^T V.
+// All three are "NT" products with both operands contiguous along k, so one staging path serves.
+//
+// Shape: 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each wave 64 x 64 =
+// 4 x 4 MFMA tiles of 16 x 16).  k advances 128 bytes per row per step (16 f64 / 32 f32).
+//   fp64: v_mfma_f64_16x16x4_f64   (C/D: row = (lane>>4) + 4*reg, col = lane&15)
+//   fp32: v_mfma_f32_16x16x4_f32   (C/D: row = (lane>>4)*4 + reg, col = lane&15)
+// Both take ONE scalar of A and of B per lane (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]).
+// A lane therefore needs, per 16-row fragment, the k-values {g, g+4, g+8, ...} (g = lane>>4).
+// Because the sum over k is order independent we hand lane group g the 16-byte chunk 4q+g of the
+// 128-byte row instead (2 f64 / 4 f32 consecutive k per chunk): one ds_read_b128 then feeds
+// 2 (f64) or 4 (f32) MFMA k-steps, and A and B use the same permutation so products pair up.
+//
+// LDS image per operand and stage: [128 rows][8 chunks of 16 B], chunk index XOR ((row>>1)&7).
+//   - staging writes: 8 consecutive lanes write the 8 chunks of one row -> 8 distinct 16-B slots,
+//   - fragment reads (ds_read_b128, 16 rows at one chunk index): (row&1, (row>>1)&7) is distinct
+//     over 16 consecutive rows -> conflict free.
+// Two stages (64 KB) + register prefetch of the next k-tile; one barrier per k-tile; two workgroups
+// per CU (launch bound 2 waves/SIMD) hide each other's barrier and epilogue.
+//
+// Requirements (the library pads every matrix to multiples of 128 with zeros / identity):
+//   m % 128 == 0, n % 128 == 0, k % 128 == 0, leading dimensions multiples of 4 elements,
+//   16-byte aligned base pointers.  In-place use (D aliasing A) is safe iff n == 128: a
+//   workgroup then reads exactly the rows it later overwrites and finishes reading first.
+#include "common.h"
+
+namespace algp {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct MF;
+template <>
+struct MF<double> {
+    using acc_t = v4d;
+    using chunk_t = v2d;
+    static constexpr int EPC = 2;
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct MF<float> {
+    using acc_t = v4f;
+    using chunk_t = v4f;
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+template <typename T>
+struct GemmArgs {
+    const T* A;
+    const T* B;
+    const T* C;
+    T* D;
+    int64_t lda, ldb, ldc, ldd;
+    int tiles_m, tiles_n, ktiles;
+    T alpha, beta;
+    int lower_only;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    using chunk_t = typename F::chunk_t;
+    constexpr int EPC = F::EPC;
+    constexpr int BK = 8 * EPC;
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * 128];
+
+    // ---- workgroup -> tile: XCD-aware (blocks b, b+8, ... share an L2), bijective remap ----
+    const int nwg = gridDim.x;
+    int sid;
+    {
+        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    int bm, bn;
+    if (g.lower_only) {
+        bm = (int)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= sid) ++bm;
+        while ((int64_t)bm * (bm + 1) / 2 > sid) --bm;
+        bn = sid - (int)((int64_t)bm * (bm + 1) / 2);
+    } else {
+        bm = sid / g.tiles_n;
+        bn = sid - bm * g.tiles_n;
+    }
+    const int64_t m0 = (int64_t)bm * 128, n0 = (int64_t)bn * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- staging assignment: chunk id = tid + 256*i -> row = (tid>>3) + 32*i, chunk = tid&7 ----
+    const int lrow = tid >> 3, lch = tid & 7;
+    const T* Ag = g.A + (m0 + lrow) * g.lda + lch * EPC;
+    const T* Bg = g.B + (n0 + lrow) * g.ldb + lch * EPC;
+    const int woff = lrow * 128 + ((lch ^ ((lrow >> 1) & 7)) << 4);   // (row+32i)>>1 & 7 is i-independent
+
+    chunk_t ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const chunk_t*>(Ag + (int64_t)(32 * i) * g.lda + (int64_t)kt * BK);
+            rb[i] = *reinterpret_cast<const chunk_t*>(Bg + (int64_t)(32 * i) * g.ldb + (int64_t)kt * BK);
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* As = smem + stage * 32768;
+        char* Bs = As + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<chunk_t*>(As + woff + i * 4096) = ra[i];
+            *reinterpret_cast<chunk_t*>(Bs + woff + i * 4096) = rb[i];
+        }
+    };
+
+    // ---- fragment read offsets: row = w*64 + t*16 + (lane&15); swizzle = (lane&15)>>1 ----
+    const int fr = lane & 15, fg = lane >> 4, fsw = fr >> 1;
+    const int aoff = (wr * 64 + fr) * 128;
+    const int boff = (wc * 64 + fr) * 128;
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < g.ktiles; ++kt) {
+        const bool more = (kt + 1 < g.ktiles);
+        if (more) gload(kt + 1);
+        const char* As = smem + cur * 32768;
+        const char* Bs = As + 16384;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int coff = (((4 * q + fg) ^ fsw) << 4);
+            chunk_t a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 2048 + coff);
+                b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 2048 + coff);
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: D = alpha*acc + beta*C ----
+    const T alpha = g.alpha, beta = g.beta;
+    const bool use_c = (beta != (T)0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t gj = n0 + wc * 64 + j * 16 + fr;
+                T v = alpha * acc[i][j][r];
+                if (use_c) v += beta * g.C[gi * g.ldc + gj];
+                g.D[gi * g.ldd + gj] = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+                   int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
+                   int64_t ldd, int lower_only) {
+    if (m <= 0 || n <= 0) return ALGP_OK;
+    if (m % 128 || n % 128 || k % 128 || k <= 0 || lda % 4 || ldb % 4)
+        return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: operands must be padded to multiples of 128");
+    if (lower_only && m != n) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: lower_only needs a square output");
+    GemmArgs<T> g;
+    g.A = A; g.B = B; g.C = C; g.D = D;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldd = ldd;
+    g.tiles_m = (int)(m / 128);
+    g.tiles_n = (int)(n / 128);
+    g.ktiles = (int)(k / (8 * MF<T>::EPC));
+    g.alpha = alpha; g.beta = beta;
+    g.lower_only = lower_only;
+    const int64_t tiles = lower_only ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
+    if (tiles > 0x7fffffff) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: grid too large");
+    const double flops = 2.0 * 128.0 * 128.0 * (double)k * (double)tiles;
+    const double bytes = sizeof(T) * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
+                                      (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
+    ProfScope ps(c, klass, flops, bytes);
+    hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, c->stream, g);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+
+template int gemm_nt_launch<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
+                                    const double*, int64_t, double, const double*, int64_t, double*, int64_t, int);
+template int gemm_nt_launch<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
+                                   const float*, int64_t, float, const float*, int64_t, float*, int64_t, int);
+
+// ---------------------------------------------------------------------------------------------
+// MFMA fragment-layout probe (exact integer data, asymmetric B).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void mfma_probe_kernel(int* mismatches) {
+    using F = MF<T>;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kk = lane >> 4;
+    const T a = (T)(i * 4 + kk + 1);               // A[i][k]
+    const T b = (T)((kk + 1) * 17 + i * 3);        // B[k][j], j = lane&15
+    typename F::acc_t acc;
+    for (int r = 0; r < 4; ++r) acc[r] = (T)0;
+    acc = F::mfma(a, b, acc);
+    int bad = 0;
+    for (int r = 0; r < 4; ++r) {
+        const int row = F::row_of(lane, r), col = lane & 15;
+        double want = 0;
+        for (int k = 0; k < 4; ++k) want += (double)(row * 4 + k + 1) * (double)((k + 1) * 17 + col * 3);
+        if ((double)acc[r] != want) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+template <typename T>
+int test_mfma_launch(algp_ctx* c, int* mismatches_dev) {
+    hipLaunchKernelGGL(mfma_probe_kernel<T>, dim3(1), dim3(64), 0, c->stream, mismatches_dev);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int test_mfma_launch<double>(algp_ctx*, int*);
+template int test_mfma_launch<float>(algp_ctx*, int*);
+
+}  // namespace algp

@@ -1,0 +1,240 @@
+// kmat.hip -- kernel-matrix build: ScaleKernel(RBF-ARD) / ScaleKernel(Matern-1.5) values, the
+// per-point white-noise diagonal and the likelihood-noise diagonal in one pass.
+//
+// Replaces GPR.cov_mat (reference models.py:161-181): gpytorch materialises an n1 x n2 x D
+// difference tensor, then np.diag(var) and np.eye(n) allocate two more dense n x n arrays just to
+// add a diagonal (models.py:175-180).  Here every output element is produced once, in registers,
+// and stored once: the kernel is HBM-write bound (s * n1 * n2 bytes).
+//
+// Layout: coordinates are pre-scaled by 1/lengthscale and zero padded to DP in {2,4,8} columns
+// (scale_coords), so the distance loop is fully unrolled.  A 256-thread workgroup produces a
+// 32-row x (64*VEC)-column tile: each lane owns VEC = 16 B / sizeof(T) adjacent columns (its
+// column coordinates stay in registers), each wave walks 8 rows whose coordinates are wave-uniform
+// loads; every store instruction of a wave writes 1 KiB contiguous.
+#include "common.h"
+
+namespace algp {
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    static constexpr int N = 2;
+};
+template <>
+struct Vec16<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int N = 4;
+};
+
+template <typename T>
+struct KmatArgs {
+    const T* X1;            // scaled coords of the row side   (n x DP)
+    const T* X2;            // scaled coords of the column side
+    const T* Cp;            // explicit pool covariance or null
+    int64_t n_pool;
+    const int64_t* ridx;    // row -> pool index (null: identity)
+    const int64_t* cidx;    // col -> pool index (null: identity)
+    int64_t rows, rows_pad, cols, cols_pad;
+    int64_t row_base;       // first row handled by this launch (gridDim.y is limited to 65535)
+    const T* diag_add;      // per-row value added where pool indices coincide (null: none)
+    T noise_on_equal;       // added where pool indices coincide
+    int same_pool;          // row and column indices address the same pool (equality is meaningful)
+    const int* unit;        // unit[r] >= 0: row r is the unit vector e_{unit[r]} (null: none)
+    int identity_pad;
+    int kernel;
+    T outputscale;
+    T* out;
+    int64_t ldo;
+};
+
+template <typename T>
+__device__ __forceinline__ T kval(int kernel, T os, T r2) {
+    if (kernel == ALGP_KERNEL_RBF) return os * exp((T)-0.5 * r2);
+    const T r = sqrt(r2) * (T)1.7320508075688772;
+    return os * ((T)1 + r) * exp(-r);
+}
+
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
+    constexpr int VEC = Vec16<T>::N;
+    using vec_t = typename Vec16<T>::type;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+    if (c0 >= a.cols_pad) return;
+    const int64_t r0 = a.row_base + (int64_t)blockIdx.y * 32 + wave * 8;
+
+    T xc[VEC][DP];
+    int64_t pc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const int64_t c = c0 + v;
+        pc[v] = -1;
+        if (c < a.cols) {
+            pc[v] = a.cidx ? a.cidx[c] : c;
+            if (!a.Cp) {
+#pragma unroll
+                for (int d = 0; d < DP; ++d) xc[v][d] = a.X2[pc[v] * DP + d];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xc[v][d] = (T)0;
+        }
+    }
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+        const int64_t r = r0 + rr;
+        if (r >= a.rows_pad) break;
+        vec_t o;
+        if (r < a.rows) {
+            const int u = a.unit ? a.unit[r] : -1;
+            const int64_t pr = a.ridx ? a.ridx[r] : r;
+            T xr[DP];
+            if (u < 0 && !a.Cp) {
+#pragma unroll
+                for (int d = 0; d < DP; ++d) xr[d] = a.X1[pr * DP + d];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int64_t c = c0 + v;
+                T val = (T)0;
+                if (c < a.cols) {
+                    if (u >= 0) {
+                        val = (c == (int64_t)u) ? (T)1 : (T)0;
+                    } else {
+                        if (a.Cp) {
+                            val = a.Cp[pr * a.n_pool + pc[v]];
+                        } else {
+                            T r2 = (T)0;
+#pragma unroll
+                            for (int d = 0; d < DP; ++d) {
+                                const T df = xr[d] - xc[v][d];
+                                r2 += df * df;
+                            }
+                            val = kval<T>(a.kernel, a.outputscale, r2);
+                        }
+                        if (a.same_pool && pr == pc[v]) {
+                            val += a.noise_on_equal;
+                            if (a.diag_add) val += a.diag_add[r];
+                        }
+                    }
+                } else if (a.identity_pad && c == r) {
+                    val = (T)1;
+                }
+                o[v] = val;
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = (a.identity_pad && (c0 + v) == r) ? (T)1 : (T)0;
+        }
+        *reinterpret_cast<vec_t*>(a.out + r * a.ldo + c0) = o;
+    }
+}
+
+template <typename T>
+static int kmat_dispatch(algp_ctx* c, const KmatArgs<T>& a, int DP) {
+    constexpr int VEC = Vec16<T>::N;
+    if (a.rows_pad <= 0 || a.cols_pad <= 0) return ALGP_OK;
+    const int64_t gx = (a.cols_pad + 64 * VEC - 1) / (64 * VEC);
+    const int64_t gy = (a.rows_pad + 31) / 32;
+    const double elems = (double)a.rows_pad * (double)a.cols_pad;
+    ProfScope ps(c, ALGP_PROF_KMAT, elems * (3.0 * DP + 2.0), sizeof(T) * elems);
+    const int64_t ymax = 65535;
+    for (int64_t y0 = 0; y0 < gy; y0 += ymax) {
+        KmatArgs<T> b = a;
+        const int64_t ny = (gy - y0 < ymax) ? gy - y0 : ymax;
+        b.row_base = y0 * 32;
+        dim3 grid((unsigned)gx, (unsigned)ny);
+        if (DP == 2) hipLaunchKernelGGL((kmat_kernel<T, 2>), grid, dim3(256), 0, c->stream, b);
+        else if (DP == 4) hipLaunchKernelGGL((kmat_kernel<T, 4>), grid, dim3(256), 0, c->stream, b);
+        else hipLaunchKernelGGL((kmat_kernel<T, 8>), grid, dim3(256), 0, c->stream, b);
+    }
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+
+template <typename T>
+int kmat_launch(algp_ctx* c, const KmatSrc& s, const int64_t* ridx, int64_t rows, int64_t rows_pad,
+                const int64_t* cidx, int64_t cols, int64_t cols_pad, const T* diag_add, int add_noise_on_equal,
+                const int* unit, int identity_pad, T* out, int64_t ldo) {
+    KmatArgs<T> a;
+    a.X1 = (const T*)s.Xs;
+    a.X2 = (const T*)s.Xs;
+    a.Cp = (const T*)s.Cp;
+    a.n_pool = s.n_pool;
+    a.ridx = ridx;
+    a.cidx = cidx;
+    a.rows = rows; a.rows_pad = rows_pad; a.cols = cols; a.cols_pad = cols_pad;
+    a.diag_add = diag_add;
+    a.noise_on_equal = (T)(add_noise_on_equal ? s.noise : 0.0);
+    a.same_pool = 1;
+    a.unit = unit;
+    a.identity_pad = identity_pad;
+    a.kernel = s.kernel;
+    a.outputscale = (T)s.outputscale;
+    a.out = out;
+    a.ldo = ldo;
+    return kmat_dispatch<T>(c, a, s.DP);
+}
+template int kmat_launch<double>(algp_ctx*, const KmatSrc&, const int64_t*, int64_t, int64_t, const int64_t*, int64_t,
+                                 int64_t, const double*, int, const int*, int, double*, int64_t);
+template int kmat_launch<float>(algp_ctx*, const KmatSrc&, const int64_t*, int64_t, int64_t, const int64_t*, int64_t,
+                                int64_t, const float*, int, const int*, int, float*, int64_t);
+
+template <typename T>
+int kmat_xy_launch(algp_ctx* c, const T* xs1, int64_t n1, const T* xs2, int64_t n2, int symmetric,
+                   const T* diag_add, double add_noise, T* out, int64_t ldo) {
+    KmatArgs<T> a;
+    a.X1 = xs1;
+    a.X2 = symmetric ? xs1 : xs2;
+    a.Cp = nullptr;
+    a.n_pool = 0;
+    a.ridx = nullptr;
+    a.cidx = nullptr;
+    a.rows = n1; a.rows_pad = n1; a.cols = n2; a.cols_pad = round_up(n2, Vec16<T>::N);
+    a.diag_add = symmetric ? diag_add : nullptr;
+    a.noise_on_equal = (T)(symmetric ? add_noise : 0.0);
+    a.same_pool = symmetric;
+    a.unit = nullptr;
+    a.identity_pad = 0;
+    a.kernel = c->hyp.kernel;
+    a.outputscale = (T)c->hyp.outputscale;
+    a.out = out;
+    a.ldo = ldo;
+    return kmat_dispatch<T>(c, a, c->hyp.DP);
+}
+template int kmat_xy_launch<double>(algp_ctx*, const double*, int64_t, const double*, int64_t, int, const double*,
+                                    double, double*, int64_t);
+template int kmat_xy_launch<float>(algp_ctx*, const float*, int64_t, const float*, int64_t, int, const float*, double,
+                                   float*, int64_t);
+
+// xs[i][d] = x[i][d] / lengthscale_d for d < D, 0 for D <= d < DP
+struct InvLs {
+    double v[MAXD];
+};
+
+template <typename T>
+__global__ void scale_coords_kernel(const T* x, int64_t n, int D, int DP, InvLs inv_ls8, T* xs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * DP) return;
+    const int64_t p = i / DP;
+    const int d = (int)(i - p * DP);
+    xs[i] = d < D ? x[p * D + d] * (T)inv_ls8.v[d] : (T)0;
+}
+
+template <typename T>
+int scale_coords_launch(algp_ctx* c, const T* x, int64_t n, T* xs) {
+    if (n <= 0) return ALGP_OK;
+    InvLs il;
+    for (int d = 0; d < MAXD; ++d) il.v[d] = c->hyp.inv_ls[d];
+    const int64_t tot = n * c->hyp.DP;
+    hipLaunchKernelGGL(scale_coords_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, x, n,
+                       c->hyp.D, c->hyp.DP, il, xs);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int scale_coords_launch<double>(algp_ctx*, const double*, int64_t, double*);
+template int scale_coords_launch<float>(algp_ctx*, const float*, int64_t, float*);
+
+}  // namespace algp

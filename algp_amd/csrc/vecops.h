@@ -1,0 +1,29 @@
+// launchers defined in vecops.hip
+#pragma once
+#include "common.h"
+namespace algp {
+template <typename T>
+int cand_finalize_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const T* Cp, int64_t n_pool,
+                         T prior_const, const T* extra, const T* ss, const T* dot, T ybar, T* dstat, T* mu,
+                         unsigned char* alive);
+template <typename T>
+int score_launch(algp_ctx* c, int64_t M, const int* ckind, const unsigned char* alive, const T* dstat, double ss,
+                 double delta, const double* extra, double* out);
+int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx);
+template <typename T>
+int pick_update_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
+                       int64_t n_pool, int DP, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
+                       const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col);
+template <typename T>
+int kgemv_launch(algp_ctx* c, int64_t M, const int64_t* qidx, const T* Xs, int DP, int64_t N, const int64_t* aidx,
+                 const T* alpha, int kernel, T os, T ybar, T* mu);
+template <typename T>
+int pad_identity_launch(algp_ctx* c, T* A, int64_t n, int64_t npad, int64_t ld);
+template <typename T>
+int set_identity_launch(algp_ctx* c, T* A, int64_t npad, int64_t ld);
+template <typename T>
+int to_double_launch(algp_ctx* c, double* dst, const T* src, int64_t n);
+// inverse of the NB x NB lower-triangular diagonal block at A (no factorisation)
+template <typename T>
+int trinv_diag_launch(algp_ctx* c, const T* A, int64_t lda, T* inv_out);
+}  // namespace algp

@@ -1,0 +1,343 @@
+// vecops.hip -- the HBM-bound tail of the path: row reductions over V^T (posterior variance and
+// mean, greedy rank-1 updates), candidate scoring, argmax, and the fused kernel-GEMV for the
+// mean-only posterior.  Replaces utils.py:301, 308 and the per-candidate slogdet loop of
+// agent.py:317-347 (whose M fresh factorizations collapse to one pass over V^T per pick).
+#include "common.h"
+#include "vecops.h"
+
+namespace algp {
+
+// ---------------------------------------------------------------------------------------------
+// rows_reduce: one wave per row of V^T; 16-byte loads; ss[j] = sum v^2, dot[j] = sum v*w.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool HAS_W, bool HAS_SS>
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const T* Vt, int64_t rows, int64_t ldv, int64_t ncols,
+                                                          const T* w, T* ss, T* dot) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t nvec = ncols / VEC;           // full vectors; the tail (ncols % VEC) is handled scalar
+    for (int64_t j = wave; j < rows; j += nw) {
+        const T* row = Vt + j * ldv;
+        T s2 = (T)0, sd = (T)0;
+        for (int64_t v = lane; v < nvec; v += 64) {
+            const vec_t x = *reinterpret_cast<const vec_t*>(row + v * VEC);
+            if (HAS_W) {
+                const vec_t y = *reinterpret_cast<const vec_t*>(w + v * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sd += x[e] * y[e];
+            }
+            if (HAS_SS) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s2 += x[e] * x[e];
+            }
+        }
+        const int64_t t = nvec * VEC + lane;
+        if (t < ncols) {
+            const T x = row[t];
+            if (HAS_W) sd += x * w[t];
+            if (HAS_SS) s2 += x * x;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            if (HAS_SS) s2 += __shfl_down(s2, o, 64);
+            if (HAS_W) sd += __shfl_down(sd, o, 64);
+        }
+        if (lane == 0) {
+            if (HAS_SS) ss[j] = s2;
+            if (HAS_W) dot[j] = sd;
+        }
+    }
+}
+
+template <typename T>
+int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t ncols, const T* w, T* ss,
+                       T* dot) {
+    if (rows <= 0) return ALGP_OK;
+    int64_t g = (rows + 3) / 4;
+    if (g > 8192) g = 8192;
+    ProfScope ps(c, ALGP_PROF_ROWS, 2.0 * rows * ncols * ((w ? 1 : 0) + (ss ? 1 : 0)), sizeof(T) * (double)rows * ncols);
+    dim3 grid((unsigned)g), blk(256);
+    if (w && ss) hipLaunchKernelGGL((rows_reduce_kernel<T, true, true>), grid, blk, 0, c->stream, Vt, rows, ldv, ncols, w, ss, dot);
+    else if (w) hipLaunchKernelGGL((rows_reduce_kernel<T, true, false>), grid, blk, 0, c->stream, Vt, rows, ldv, ncols, w, ss, dot);
+    else if (ss) hipLaunchKernelGGL((rows_reduce_kernel<T, false, true>), grid, blk, 0, c->stream, Vt, rows, ldv, ncols, w, ss, dot);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int rows_reduce_launch<double>(algp_ctx*, const double*, int64_t, int64_t, int64_t, const double*, double*, double*);
+template int rows_reduce_launch<float>(algp_ctx*, const float*, int64_t, int64_t, int64_t, const float*, float*, float*);
+
+// ---------------------------------------------------------------------------------------------
+// candidate finalize: dstat = prior - ss (ordinary) | ss (unit row: [S^-1]_jj); mu = ybar + dot
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cand_finalize_kernel(int64_t M, const int* ckind, const int64_t* cidx, const T* Cp, int64_t n_pool,
+                                     T prior_const, const T* extra, const T* ss, const T* dot, T ybar, T* dstat,
+                                     T* mu, unsigned char* alive) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const bool unit = ckind && ckind[j] >= 0;
+    T prior = Cp ? Cp[cidx[j] * n_pool + cidx[j]] : prior_const;
+    if (extra) prior += extra[j];
+    dstat[j] = unit ? ss[j] : prior - ss[j];
+    mu[j] = ybar + dot[j];
+    alive[j] = 1;
+}
+
+template <typename T>
+int cand_finalize_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const T* Cp, int64_t n_pool,
+                         T prior_const, const T* extra, const T* ss, const T* dot, T ybar, T* dstat, T* mu,
+                         unsigned char* alive) {
+    if (M <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(cand_finalize_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, M, ckind,
+                       cidx, Cp, n_pool, prior_const, extra, ss, dot, ybar, dstat, mu, alive);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int cand_finalize_launch<double>(algp_ctx*, int64_t, const int*, const int64_t*, const double*, int64_t, double,
+                                          const double*, const double*, const double*, double, double*, double*, unsigned char*);
+template int cand_finalize_launch<float>(algp_ctx*, int64_t, const int*, const int64_t*, const float*, int64_t, float,
+                                         const float*, const float*, const float*, float, float*, float*, unsigned char*);
+
+// ---------------------------------------------------------------------------------------------
+// scores (entropy gain per candidate, agent.py:341 after telescoping)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void score_kernel(int64_t M, const int* ckind, const unsigned char* alive, const T* dstat, double ss,
+                             double delta, const double* extra, double* out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double u;
+    if (!alive[j]) {
+        u = -INFINITY;
+    } else {
+        const double d = (double)dstat[j];
+        if (ckind[j] >= 0) u = 0.5 * log1p(delta * d);
+        else u = ENT_CONST + 0.5 * log(d + ss);
+        if (extra) u += extra[j];
+    }
+    out[j] = u;
+}
+
+template <typename T>
+int score_launch(algp_ctx* c, int64_t M, const int* ckind, const unsigned char* alive, const T* dstat, double ss,
+                 double delta, const double* extra, double* out) {
+    if (M <= 0) return ALGP_OK;
+    ProfScope ps(c, ALGP_PROF_SCORE, 4.0 * M, (sizeof(T) + 13.0) * M);
+    hipLaunchKernelGGL(score_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, M, ckind, alive,
+                       dstat, ss, delta, extra, out);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int score_launch<double>(algp_ctx*, int64_t, const int*, const unsigned char*, const double*, double, double,
+                                  const double*, double*);
+template int score_launch<float>(algp_ctx*, int64_t, const int*, const unsigned char*, const float*, double, double,
+                                 const double*, double*);
+
+// first maximum (np.argmax semantics, agent.py:349): larger value wins, ties go to the smaller index
+__global__ __launch_bounds__(1024) void argmax_kernel(const double* s, int64_t M, double* out_val, int64_t* out_idx) {
+    __shared__ double sv[16];
+    __shared__ int64_t si[16];
+    double bv = -INFINITY;
+    int64_t bi = -1;
+    for (int64_t j = threadIdx.x; j < M; j += 1024) {
+        const double v = s[j];
+        if (bi < 0 || v > bv) {     // j ascending per thread: strict > keeps the first maximum
+            if (!(v != v)) { bv = v; bi = j; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(bv, o, 64);
+        const int64_t oi = __shfl_down(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] < bi))) { bv = sv[w]; bi = si[w]; }
+        *out_val = bv;
+        *out_idx = bi;
+    }
+}
+
+int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx) {
+    ProfScope ps(c, ALGP_PROF_SCORE, (double)M, 8.0 * M);
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, s, M, out_val, out_idx);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// greedy commit: r_j = (b'_j - t_j) * scale ; dstat_j -= r^2 (ordinary) / += r^2 (unit row);
+// V^T[j][ncols] = r_j.   b'_j = C(pick, j) when the pick is a new site and row j is ordinary.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DP>
+__global__ void pick_update_kernel(int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
+                                   int64_t n_pool, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
+                                   const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const bool unit = ckind[j] >= 0;
+    T bp = (T)0;
+    if (!pick_in_train && !unit) {
+        const int64_t pj = cidx[j];
+        if (Cp) {
+            bp = Cp[pick_pool * n_pool + pj];
+        } else {
+            T r2 = (T)0;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const T df = Xs[pick_pool * DP + d] - Xs[pj * DP + d];
+                r2 += df * df;
+            }
+            if (kernel == ALGP_KERNEL_RBF) bp = os * exp((T)-0.5 * r2);
+            else {
+                const T r = sqrt(r2) * (T)1.7320508075688772;
+                bp = os * ((T)1 + r) * exp(-r);
+            }
+            if (pj == pick_pool) bp += noise;
+        }
+    }
+    const T r = (bp - tvec[j]) * scale;
+    dstat[j] += unit ? r * r : -(r * r);
+    Vt[j * ldv + col] = r;
+}
+
+template <typename T>
+int pick_update_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
+                       int64_t n_pool, int DP, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
+                       const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col) {
+    if (M <= 0) return ALGP_OK;
+    ProfScope ps(c, ALGP_PROF_ROWS, 8.0 * M, 4.0 * sizeof(T) * M);
+    dim3 grid((unsigned)((M + 255) / 256)), blk(256);
+#define ALGP_PU(DPV)                                                                                            \
+    hipLaunchKernelGGL((pick_update_kernel<T, DPV>), grid, blk, 0, c->stream, M, ckind, cidx, Xs, Cp, n_pool, \
+                       pick_pool, pick_in_train, kernel, os, noise, tvec, scale, dstat, Vt, ldv, col)
+    if (DP == 2) ALGP_PU(2);
+    else if (DP == 4) ALGP_PU(4);
+    else ALGP_PU(8);
+#undef ALGP_PU
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int pick_update_launch<double>(algp_ctx*, int64_t, const int*, const int64_t*, const double*, const double*,
+                                        int64_t, int, int64_t, int, int, double, double, const double*, double, double*,
+                                        double*, int64_t, int64_t);
+template int pick_update_launch<float>(algp_ctx*, int64_t, const int*, const int64_t*, const float*, const float*,
+                                       int64_t, int, int64_t, int, int, float, float, const float*, float, float*, float*,
+                                       int64_t, int64_t);
+
+// ---------------------------------------------------------------------------------------------
+// fused kernel-GEMV: mu_j = ybar + sum_a k(x_j, x_a) alpha_a, K never materialised (utils.py:301).
+// One wave per output; lanes stride over the train set (coordinates and alpha are L2 resident).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void kgemv_kernel(int64_t M, const int64_t* qidx, const T* Xs, int64_t N,
+                                                    const int64_t* aidx, const T* alpha, int kernel, T os, T ybar,
+                                                    T* mu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t j = wave; j < M; j += nw) {
+        const int64_t pj = qidx[j];
+        T xj[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xj[d] = Xs[pj * DP + d];
+        T s = (T)0;
+        for (int64_t a = lane; a < N; a += 64) {
+            const int64_t pa = aidx[a];
+            T r2 = (T)0;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const T df = xj[d] - Xs[pa * DP + d];
+                r2 += df * df;
+            }
+            T kv;
+            if (kernel == ALGP_KERNEL_RBF) kv = os * exp((T)-0.5 * r2);
+            else {
+                const T r = sqrt(r2) * (T)1.7320508075688772;
+                kv = os * ((T)1 + r) * exp(-r);
+            }
+            s += kv * alpha[a];
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) mu[j] = ybar + s;
+    }
+}
+
+template <typename T>
+int kgemv_launch(algp_ctx* c, int64_t M, const int64_t* qidx, const T* Xs, int DP, int64_t N, const int64_t* aidx,
+                 const T* alpha, int kernel, T os, T ybar, T* mu) {
+    if (M <= 0) return ALGP_OK;
+    int64_t g = (M + 3) / 4;
+    if (g > 8192) g = 8192;
+    ProfScope ps(c, ALGP_PROF_KMAT, (double)M * N * (3.0 * DP + 4.0), sizeof(T) * (double)(M + N) * (DP + 1));
+    dim3 grid((unsigned)g), blk(256);
+    if (DP == 2) hipLaunchKernelGGL((kgemv_kernel<T, 2>), grid, blk, 0, c->stream, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
+    else if (DP == 4) hipLaunchKernelGGL((kgemv_kernel<T, 4>), grid, blk, 0, c->stream, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
+    else hipLaunchKernelGGL((kgemv_kernel<T, 8>), grid, blk, 0, c->stream, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int kgemv_launch<double>(algp_ctx*, int64_t, const int64_t*, const double*, int, int64_t, const int64_t*,
+                                  const double*, int, double, double, double*);
+template int kgemv_launch<float>(algp_ctx*, int64_t, const int64_t*, const float*, int, int64_t, const int64_t*,
+                                 const float*, int, float, float, float*);
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pad_identity_kernel(T* A, int64_t n, int64_t npad, int64_t ld) {
+    // rows/cols >= n of an npad x npad matrix become identity (the interior is left alone)
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npad * npad) return;
+    const int64_t i = e / npad, j = e - i * npad;
+    if (i >= n || j >= n) A[i * ld + j] = (i == j) ? (T)1 : (T)0;
+}
+template <typename T>
+int pad_identity_launch(algp_ctx* c, T* A, int64_t n, int64_t npad, int64_t ld) {
+    const int64_t tot = npad * npad;
+    hipLaunchKernelGGL(pad_identity_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, A, n, npad, ld);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int pad_identity_launch<double>(algp_ctx*, double*, int64_t, int64_t, int64_t);
+template int pad_identity_launch<float>(algp_ctx*, float*, int64_t, int64_t, int64_t);
+
+template <typename T>
+__global__ void set_identity_kernel(T* A, int64_t npad, int64_t ld) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npad * npad) return;
+    const int64_t i = e / npad, j = e - i * npad;
+    A[i * ld + j] = (i == j) ? (T)1 : (T)0;
+}
+template <typename T>
+int set_identity_launch(algp_ctx* c, T* A, int64_t npad, int64_t ld) {
+    const int64_t tot = npad * npad;
+    hipLaunchKernelGGL(set_identity_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, A, npad, ld);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int set_identity_launch<double>(algp_ctx*, double*, int64_t, int64_t);
+template int set_identity_launch<float>(algp_ctx*, float*, int64_t, int64_t);
+
+template <typename T>
+__global__ void add_doubles_kernel(double* dst, const T* src, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] = (double)src[e];
+}
+template <typename T>
+int to_double_launch(algp_ctx* c, double* dst, const T* src, int64_t n) {
+    if (n <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(add_doubles_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dst, src, n);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int to_double_launch<double>(algp_ctx*, double*, const double*, int64_t);
+template int to_double_launch<float>(algp_ctx*, double*, const float*, int64_t);
+
+}  // namespace algp

@@ -1,0 +1,177 @@
+/*
+ * algp_hip.h -- C ABI of libalgp_hip.so: the MI355X (gfx950) GP-inference hot path of sumitsk/algp.
+ *
+ * The reference has NO native/FFI layer (it is 8 Python files); its seam for this path is the
+ * duck-typed Python surface
+ *     GPR.cov_mat / GPR.set_train_data            (reference models.py:126-135, 161-181)
+ *     predictive_distribution / entropy_from_cov  (reference utils.py:188-194, 293-319)
+ *     Agent._post_update / greedy / best_path     (reference agent.py:89-90, 295-403)
+ * plus NumPy inv / slogdet / dot / argmax.  This header is the boundary a maintainer would bind
+ * (ctypes) to route those calls onto the GPU.  Each entry point cites the
+ * reference code it replaces.
+ *
+ * Conventions
+ *  - one opaque context per GPU; NOT thread-safe (one caller thread per ctx); every call is
+ *    synchronous at the ABI (stream-ordered inside, stream synchronised before return);
+ *  - all matrices row-major, contiguous; element type = the ctx dtype (ALGP_F32 / ALGP_F64),
+ *    passed as void*; indices int64_t; utilities / entropies / log-dets are always double;
+ *  - caller owns every host buffer; the library owns device memory inside the ctx;
+ *  - return value: 0 = ALGP_OK, otherwise an ALGP_ERR_* code; algp_last_error() gives text.
+ *    A non-positive pivot (reference: LinAlgError from inv, utils.py:300, or a silently wrong
+ *    slogdet, utils.py:193) returns ALGP_ERR_NOT_PD and algp_last_pivot() the 1-based index.
+ *  - the "pool" is the set of n field locations (reference env.X); train set and candidates are
+ *    index lists into it, exactly like Agent's static_data/mobile_data bookkeeping.
+ */
+#ifndef ALGP_HIP_H
+#define ALGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct algp_ctx algp_ctx;
+
+enum { ALGP_F32 = 0, ALGP_F64 = 1 };
+enum { ALGP_KERNEL_RBF = 0, ALGP_KERNEL_MATERN15 = 1 };          /* models.py:217-220 */
+enum { ALGP_CRIT_ENTROPY = 0, ALGP_CRIT_MUTUAL_INFORMATION = 1 };  /* agent.py:128 */
+enum {
+    ALGP_OK = 0,
+    ALGP_ERR_BAD_ARG = 1,
+    ALGP_ERR_HIP = 2,
+    ALGP_ERR_NOT_PD = 3,
+    ALGP_ERR_OOM = 4,
+    ALGP_ERR_STATE = 5,
+    ALGP_ERR_NO_DEVICE = 6
+};
+
+/* profiling classes for algp_prof_get (HIP-event timed, see DESIGN.md "measurement") */
+enum {
+    ALGP_PROF_KMAT = 0,        /* kernel-matrix build (HBM-bound)                  */
+    ALGP_PROF_GEMM_CHOL = 1,   /* MFMA GEMM launches inside the Cholesky            */
+    ALGP_PROF_GEMM_TRSM = 2,   /* MFMA GEMM launches inside the candidate TRSM      */
+    ALGP_PROF_POTRF_DIAG = 3,  /* 128x128 diagonal-block factor + inverse           */
+    ALGP_PROF_TRSV = 4,        /* vector triangular solves                           */
+    ALGP_PROF_ROWS = 5,        /* row reductions over V^T (variance, mean, updates) */
+    ALGP_PROF_SCORE = 6,       /* score + argmax                                    */
+    ALGP_PROF_GEMM_OTHER = 7,
+    ALGP_PROF_COUNT = 8
+};
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int algp_version(void);
+int algp_device_count(void);
+int algp_create(int device_id, int dtype, algp_ctx** out);
+void algp_destroy(algp_ctx* ctx);
+const char* algp_last_error(const algp_ctx* ctx);
+int64_t algp_last_pivot(const algp_ctx* ctx);
+int algp_dtype(const algp_ctx* ctx);
+
+/* ---- hyper-parameters: ExactGPModel's D+2 scalars (models.py:206-254; names run.py:35-37) ---
+ * k(x,x') = exp(log_outputscale) * exp(-1/2 sum_d ((x_d-x'_d)/exp(log_lengthscale[d]))^2)  (RBF)
+ * sigma_n^2 = exp(log_noise) (models.py:180).                                                  */
+int algp_set_hypers(algp_ctx* ctx, int kernel, int D, const double* log_lengthscale,
+                    double log_outputscale, double log_noise);
+
+/* ---- a1: GPR.cov_mat (models.py:161-181) -------------------------------------------------
+ * out[n1*n2] (host) = K(x1,x2) ; x2 == NULL -> symmetric K(x1,x1) (models.py:169-170);
+ * diag_add (len n1, may be NULL): += diag(white_noise_var) (models.py:175-176), symmetric only;
+ * add_likelihood_var: += exp(log_noise) * I (models.py:179-180), symmetric only.              */
+int algp_kernel_matrix(algp_ctx* ctx, const void* x1, int64_t n1, const void* x2, int64_t n2,
+                       const void* diag_add, int add_likelihood_var, void* out);
+
+/* ---- pool: env.X (agent.py:90) ------------------------------------------------------------
+ * algp_set_pool: coordinates n x D (kernel evaluated on the fly on the device).
+ * algp_set_pool_cov: an explicit n x n covariance that already contains sigma_n^2 on its
+ *   diagonal -- literally Agent.cov_matrix (agent.py:90) -- for callers that hand one over.   */
+int algp_set_pool(algp_ctx* ctx, const void* x, int64_t n);
+int algp_set_pool_cov(algp_ctx* ctx, const void* cov, int64_t n);
+
+/* ---- a2 + "GP-fit": GPR.set_train_data (models.py:126-135) + factorisation ----------------
+ * idx[N] pool indices, y[N] targets (mean-centred inside: models.py:129-130), var[N] per-point
+ * noise (may be NULL = 0).  algp_factorize builds S = C_AA + diag(var) (+ sigma_n^2 I unless the
+ * pool is an explicit cov that already has it), factors S = L L^T (blocked, MFMA), solves
+ * z = L^-1 (y-ybar), alpha = L^-T z, and accumulates log det S.  Replaces np.linalg.inv at
+ * utils.py:300 and slogdet at utils.py:193.                                                    */
+int algp_set_train(algp_ctx* ctx, const int64_t* idx, int64_t N, const void* y, const void* var);
+int algp_factorize(algp_ctx* ctx);
+int algp_get_logdet(algp_ctx* ctx, double* logdet);          /* log det S                        */
+int algp_get_entropy(algp_ctx* ctx, double* H);              /* N*CONST + 1/2 log det S (utils.py:188) */
+int algp_get_alpha(algp_ctx* ctx, void* alpha_out);          /* N values                         */
+int algp_get_factor(algp_ctx* ctx, void* L_out);             /* N x N lower, zeros above         */
+int algp_get_mll(algp_ctx* ctx, double* mll);                /* -1/2 y0'alpha - 1/2 logdet - N/2 log 2pi */
+
+/* ---- candidates / test points: predictive_distribution (utils.py:293-319), greedy's pool ---
+ * idx[M] pool indices.  A candidate that is itself in the train set (a mobile-sampled site,
+ * agent.py:318 only skips static ones) is detected by index equality.
+ * prior_includes_noise: 1 -> prior var = C_jj = outputscale + sigma_n^2 (greedy, agent.py:90),
+ *                       0 -> prior var = K_jj (+ extra_var[j]) (cov_xx of utils.py:297).
+ * algp_solve_candidates: V^T = B^T L^-T by blocked TRSM on MFMA, then row reductions
+ *   pv_j = prior_j - |V_j|^2, mu_j = ybar + V_j . z.                                            */
+int algp_set_candidates(algp_ctx* ctx, const int64_t* idx, int64_t M, int prior_includes_noise,
+                        const void* extra_var);
+int algp_solve_candidates(algp_ctx* ctx);
+int algp_get_posterior(algp_ctx* ctx, void* mu_out, void* var_out);      /* either may be NULL  */
+/* full M x M posterior covariance (utils.py:305) and mi = H(cov_xx) - H(cov) (utils.py:314);
+ * cov_out / mi_out may be NULL.                                                                */
+int algp_get_posterior_cov(algp_ctx* ctx, void* cov_out, double* mi_out);
+/* mean only, mu = ybar + K_xa alpha with K never materialised (utils.py:301)                   */
+int algp_posterior_mean(algp_ctx* ctx, const int64_t* idx, int64_t M, void* mu_out);
+
+/* ---- a7: Agent.greedy (agent.py:295-356) ---------------------------------------------------
+ * algp_scores: utilities of every candidate under the current state
+ *   entropy: CONST + 1/2 log(pv_j + ss) (unsampled) | 1/2 log(1 + delta s_jj) (mobile-sampled)
+ *   (identical to the reference's ent_a - cond, agent.py:341).
+ *   out: M doubles; out_is_device != 0 -> `out` is a device pointer (multi-GPU all-gather
+ *   buffers owned by the caller).  Committed candidates get -inf (agent.py:314, 318).
+ * algp_argmax: first maximum (np.argmax, agent.py:349) over the local scores.
+ * algp_commit_pick: make pool index `pool_idx` static-sampled (agent.py:352-354) and apply the
+ *   rank-1 row append to V^T and to every candidate's pv / s.  The index need not be a local
+ *   candidate (sharded scoring: every rank commits the global winner).
+ * algp_greedy: k picks on one GPU.  utilities_out (k*M doubles, local candidate order) may be
+ *   NULL; forced_picks (k pool indices) may be NULL.
+ * MI criterion (agent.py:330-339) is exact and single-GPU: it needs the pool-wide complement. */
+int algp_scores(algp_ctx* ctx, int criterion, double static_std, double mobile_std, void* out,
+                int out_is_device);
+int algp_argmax(algp_ctx* ctx, int64_t* local_pos, int64_t* pool_idx, double* value);
+int algp_commit_pick(algp_ctx* ctx, int64_t pool_idx, double static_std, double mobile_std);
+int algp_greedy(algp_ctx* ctx, int criterion, double static_std, double mobile_std, int k,
+                const int64_t* forced_picks, int64_t* picks_out, double* utilities_out);
+
+/* ---- a5 / a8: entropy_from_cov (utils.py:188-194) and set entropies for best_path --------
+ * algp_entropy_from_cov: k*CONST + 1/2 log det cov for a host k x k SPD matrix.
+ * algp_set_entropy: H(C[idx,idx] + diag(var)) for pool indices (agent.py:386-387).              */
+int algp_entropy_from_cov(algp_ctx* ctx, const void* cov, int64_t k, double* H);
+int algp_set_entropy(algp_ctx* ctx, const int64_t* idx, int64_t m, const void* var, double* H);
+/* diag((C[idx,idx] + diag(var))^-1), m values, and its entropy (MI terms agent.py:331-338)     */
+int algp_set_inverse_diag(algp_ctx* ctx, const int64_t* idx, int64_t m, const void* var,
+                          void* diag_out, double* H);
+
+/* ---- dense building blocks on host matrices (parity tests; also usable on their own) ------
+ * algp_cholesky: L (n x n lower, zeros above) of a host SPD matrix, optional log det.
+ * algp_gemm_nt: D = alpha * A(m x k) * B(n x k)^T + beta * C(m x n).
+ * algp_trsm_right_lt: X = B * L^-T for B (m x n), L (n x n lower) -- the candidate solve.     */
+int algp_cholesky(algp_ctx* ctx, const void* A, int64_t n, void* L_out, double* logdet);
+int algp_gemm_nt(algp_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const void* A,
+                 const void* B, double beta, const void* C, void* D);
+int algp_trsm_right_lt(algp_ctx* ctx, const void* L, int64_t n, const void* B, int64_t m,
+                       void* X_out);
+/* MFMA fragment-layout probe: runs one 16x16x4 MFMA per dtype on exact integer operands and
+ * returns the number of mismatching outputs (0 expected).                                      */
+int algp_selftest_mfma(algp_ctx* ctx, int* mismatches);
+
+/* ---- resident-buffer access for benchmarks / multi-GPU plumbing --------------------------- */
+int algp_sync(algp_ctx* ctx);
+int64_t algp_device_bytes(const algp_ctx* ctx);
+
+/* ---- profiling: HIP events around every launch of a class, on the ctx stream ------------- */
+int algp_prof_enable(algp_ctx* ctx, int on);
+int algp_prof_reset(algp_ctx* ctx);
+int algp_prof_get(algp_ctx* ctx, int klass, double* ms, double* flops, double* bytes,
+                  int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALGP_HIP_H */

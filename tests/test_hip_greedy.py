@@ -1,0 +1,157 @@
+"""GPU parity of the greedy / scoring path (reference agent.py:295-403) through the C-ABI,
+against the golden vectors captured from the reference and against the fp64 oracle."""
+import numpy as np
+import pytest
+
+from algp_amd import _hip
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CRIT = {'entropy': _hip.CRIT_ENTROPY, 'mutual_information': _hip.CRIT_MUTUAL_INFORMATION}
+
+
+@pytest.fixture(scope='module')
+def ctx64():
+    c = _hip.Context(np.float64)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope='module')
+def ctx32():
+    c = _hip.Context(np.float32)
+    yield c
+    c.close()
+
+
+def _setup_state(c, static, mobile, ss, sm, y=None):
+    sampled = static | mobile
+    A = np.where(sampled)[0]
+    vf = 1.0 / (1.0 / ss + 1.0 / sm)
+    var = np.where(static[A] & mobile[A], vf, np.where(static[A], ss, sm))
+    c.set_train(A, np.zeros(len(A)) if y is None else y, var)
+    c.factorize()
+    cand = np.where(~static)[0]
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    return A, cand
+
+
+CASES = [(n, kind, crit) for n in (64, 360) for kind in ('empty', 'static', 'mobile', 'both')
+         for crit in ('entropy', 'mutual_information')]
+
+
+@pytest.mark.parametrize('n,kind,crit', CASES)
+@pytest.mark.parametrize('mode', ['cov', 'coords'])
+def test_greedy_matches_reference_golden(golden, ctx64, n, kind, crit, mode):
+    g = golden('g3_greedy')
+    pre = 'g3_n%d_' % n
+    tag = pre + kind + '_' + crit
+    if tag + '_picks' not in g.files:
+        pytest.skip('not generated')
+    cov = g[pre + 'cov']                       # fp32 values, as the reference's Agent.cov_matrix
+    s0, m0 = g[pre + kind + '_static'], g[pre + kind + '_mobile']
+    picks_want = g[tag + '_picks']
+    ut_want = g[tag + '_ut']
+    c = ctx64
+    c.set_hypers(g[pre + 'log_ls'], float(g[pre + 'log_os']), float(g[pre + 'log_noise']))
+    if mode == 'cov':
+        c.set_pool_cov(cov.astype(np.float64))          # identical inputs to the reference
+        tol = 1e-7 if crit == 'entropy' else 5e-5       # MI: fp32 slogdet noise in the reference (agent.py:331)
+    else:
+        c.set_pool(g[pre + 'X'])                        # fp64 kernel vs the reference's fp32 kernel
+        tol = 2e-5 if crit == 'entropy' else 1e-4
+    A, cand = _setup_state(c, s0, m0, 0.1 ** 2, 1.0 ** 2)
+    picks, ut = c.greedy(CRIT[crit], 0.1, 1.0, 4, forced_picks=picks_want, want_utilities=True)
+    assert list(picks) == list(picks_want)
+    full = np.full((4, n), -np.inf)
+    full[:, cand] = ut
+    fin = np.isfinite(ut_want)
+    assert np.array_equal(np.isfinite(full), fin)
+    err = np.max(np.abs(full[fin] - ut_want[fin]))
+    assert err < tol * max(1.0, np.max(np.abs(ut_want[fin]))), err
+    for p in range(4):          # our own argmax is optimal within the tolerance
+        assert ut_want[p][int(np.argmax(full[p]))] >= np.max(ut_want[p][fin[p]]) - 2 * tol
+
+
+@pytest.mark.parametrize('kind', ['static', 'mobile', 'both'])
+def test_greedy_free_run_picks(golden, ctx64, kind):
+    """Without forcing: the device argmax reproduces the reference's picks where they are not
+    rounding-determined ties (non-empty states, entropy criterion)."""
+    g = golden('g3_greedy')
+    for n in (64, 360):
+        pre = 'g3_n%d_' % n
+        c = ctx64
+        c.set_hypers(g[pre + 'log_ls'], float(g[pre + 'log_os']), float(g[pre + 'log_noise']))
+        c.set_pool_cov(g[pre + 'cov'].astype(np.float64))
+        _setup_state(c, g[pre + kind + '_static'], g[pre + kind + '_mobile'], 0.01, 1.0)
+        picks = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4)
+        assert list(picks) == list(g[pre + kind + '_entropy_picks'])
+
+
+@pytest.mark.parametrize('dtname', ['f64', 'f32'])
+def test_greedy_vs_oracle_larger_field(ctx64, ctx32, dtname):
+    """30 x 30 field (the reference's default size, env.py:20-21): picks and utilities vs the
+    fp64 oracle; fp32 context within 1e-3."""
+    c = ctx64 if dtname == 'f64' else ctx32
+    rng = np.random.RandomState(11)
+    xx, yy = np.meshgrid(np.arange(30), np.arange(30))
+    X = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)
+    X = X + 0.05 * rng.standard_normal(X.shape)          # break exact lattice ties
+    n = len(X)
+    hyp = O.Hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    static = np.zeros(n, bool)
+    mobile = np.zeros(n, bool)
+    perm = rng.permutation(n)
+    static[perm[:200]] = True
+    mobile[perm[150:400]] = True
+    C = O.kernel_matrix(hyp, X) + hyp.noise * np.eye(n)
+    picks_o, ut_o = O.greedy_fast(C, static, mobile, 0.1, 1.0, 6, 'entropy')
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise)
+    c.set_pool(X)
+    A, cand = _setup_state(c, static, mobile, 0.01, 1.0)
+    picks, ut = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, forced_picks=np.array(picks_o), want_utilities=True)
+    full = np.full((6, n), -np.inf)
+    full[:, cand] = ut
+    fin = np.isfinite(ut_o)
+    tol = 1e-9 if dtname == 'f64' else 1e-3
+    assert np.max(np.abs(full[fin] - ut_o[fin])) < tol * np.max(np.abs(ut_o[fin]))
+    if dtname == 'f64':
+        assert list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 0)) == []
+        _setup_state(c, static, mobile, 0.01, 1.0)
+        assert list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)) == picks_o
+
+
+def test_commit_remote_winner_equals_local(ctx64):
+    """Sharded scoring: a rank commits a winner that is not among its local candidates; its
+    candidates' statistics must match the single-shard run."""
+    rng = np.random.RandomState(3)
+    X = rng.uniform(0, 20, (500, 2))
+    hyp = O.Hypers(np.log([2.5, 2.5]), 0.0, np.log(1e-2))
+    n = len(X)
+    static = np.zeros(n, bool)
+    mobile = np.zeros(n, bool)
+    perm = rng.permutation(n)
+    static[perm[:100]] = True
+    mobile[perm[80:200]] = True
+    c = ctx64
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise)
+    c.set_pool(X)
+    A, cand = _setup_state(c, static, mobile, 0.01, 1.0)
+    picks, ut = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 5, want_utilities=True)
+    # shard: only the second half of the candidates is local; commit the global winners
+    half = cand[len(cand) // 2:]
+    vf = 1.0 / (1 / 0.01 + 1 / 1.0)
+    var = np.where(static[A] & mobile[A], vf, np.where(static[A], 0.01, 1.0))
+    c.set_train(A, np.zeros(len(A)), var)
+    c.factorize()
+    c.set_candidates(half, prior_includes_noise=True)
+    c.solve_candidates()
+    for p in range(5):
+        s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        want = ut[p][len(cand) // 2:]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(s), fin)
+        assert np.max(np.abs(s[fin] - want[fin])) < 1e-10
+        c.commit_pick(int(picks[p]), 0.1, 1.0)
