@@ -59,6 +59,7 @@ SIGNATURES = {
                                C.c_double, C.c_void_p, C.c_void_p]),
     'algp_trsm_right_lt': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     'algp_selftest_mfma': (C.c_int, [_c_ctx, C.POINTER(C.c_int)]),
+    'algp_bench_gemm': (C.c_int, [_c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _dblp]),
     'algp_sync': (C.c_int, [_c_ctx]),
     'algp_device_bytes': (C.c_int64, [_c_ctx]),
     'algp_prof_enable': (C.c_int, [_c_ctx, C.c_int]),
@@ -335,6 +336,12 @@ class Context(object):
         v = C.c_int()
         self._check(self.lib.algp_selftest_mfma(self.h, C.byref(v)))
         return v.value
+
+    def bench_gemm(self, m, n, k, variant=1, lower_only=False, beta_one=True, reps=5):
+        ms = C.c_double()
+        self._check(self.lib.algp_bench_gemm(self.h, m, n, k, int(variant), int(bool(lower_only)), int(bool(beta_one)),
+                                             int(reps), C.byref(ms)))
+        return ms.value
 
     # -- misc ----------------------------------------------------------------------
     def sync(self):

@@ -805,8 +805,12 @@ int algp_set_hypers(algp_ctx* c, int kernel, int D, const double* log_ls, double
     CHECK_CTX(c);
     if (D < 1 || D > MAXD || !log_ls) return fail(c, ALGP_ERR_BAD_ARG, "set_hypers: 1 <= D <= 8 required");
     if (kernel != ALGP_KERNEL_RBF && kernel != ALGP_KERNEL_MATERN15) return fail(c, ALGP_ERR_BAD_ARG, "set_hypers: unknown kernel");
-    if (c->hyp.set && c->hyp.D != D && c->n_pool > 0 && !c->pool_is_cov)
-        return fail(c, ALGP_ERR_STATE, "set_hypers: input dimension changed while a pool is resident");
+    if (c->hyp.set && c->hyp.D != D && c->n_pool > 0 && !c->pool_is_cov) {
+        // the resident coordinates have another width: drop the pool, the caller sets a new one
+        c->n_pool = 0;
+        c->N = 0;
+        c->pos_in_train.clear();
+    }
     c->hyp.kernel = kernel;
     c->hyp.D = D;
     c->hyp.DP = D <= 2 ? 2 : (D <= 4 ? 4 : 8);
@@ -972,6 +976,18 @@ int algp_selftest_mfma(algp_ctx* c, int* mismatches) {
     CHECK_CTX(c);
     if (!mismatches) return fail(c, ALGP_ERR_BAD_ARG, "selftest: bad arguments");
     return Impl<double>::selftest(c, mismatches);
+}
+
+int algp_bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lower_only, int beta_one, int reps,
+                    double* ms) {
+    CHECK_CTX(c);
+    if (!ms || m <= 0 || n <= 0 || k <= 0 || reps <= 0) return fail(c, ALGP_ERR_BAD_ARG, "bench_gemm: bad arguments");
+    const bool was = c->prof_on;
+    c->prof_on = false;
+    int rc = c->dtype == ALGP_F64 ? bench_gemm<double>(c, m, n, k, variant, lower_only, beta_one, reps, ms)
+                                  : bench_gemm<float>(c, m, n, k, variant, lower_only, beta_one, reps, ms);
+    c->prof_on = was;
+    return rc;
 }
 
 int algp_sync(algp_ctx* c) { CHECK_CTX(c); return sync(c); }

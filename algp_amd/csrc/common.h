@@ -178,5 +178,8 @@ int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int6
 
 template <typename T>
 int test_mfma_launch(algp_ctx* c, int* mismatches_dev);
+template <typename T>
+int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lower_only, int beta_one, int reps,
+               double* ms_out);
 
 }  // namespace algp

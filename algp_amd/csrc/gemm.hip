@@ -29,6 +29,8 @@
 
 namespace algp {
 
+int g_gemm_variant = 0;   // 0 = register-staged (default), 1 = LDS-DMA staging (kept for A/B benchmarking)
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -69,7 +71,7 @@ struct GemmArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     using chunk_t = typename F::chunk_t;
@@ -168,22 +170,177 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
         cur ^= 1;
     }
 
-    // ---- epilogue: D = alpha*acc + beta*C ----
+    // ---- epilogue: D = alpha*acc + beta*C; all C loads of a 16-row slab are issued before use ----
     const T alpha = g.alpha, beta = g.beta;
-    const bool use_c = (beta != (T)0);
+    if (beta != (T)0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
+            T cv[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t gj = n0 + wc * 64 + j * 16 + fr;
-                T v = alpha * acc[i][j][r];
-                if (use_c) v += beta * g.C[gi * g.ldc + gj];
-                g.D[gi * g.ldd + gj] = v;
+                for (int j = 0; j < 4; ++j) cv[r][j] = g.C[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
             }
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// v1: same tile and LDS image, but
+//   * staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass.  The
+//     LDS destination of one wave-instruction is linear (base + lane*16 = 8 rows x 128 B), so the
+//     XOR swizzle is applied to the per-lane SOURCE address instead (chunk = slot ^ ((row>>1)&7));
+//   * fragments double-buffered in registers: the ds_reads of the next 32-MFMA group are issued
+//     before the current group's MFMAs, so LDS latency hides under the 64-cycle MFMAs;
+//   * epilogue loads all C values first (one batch of loads, one wait), then stores.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    using chunk_t = typename F::chunk_t;
+    constexpr int EPC = F::EPC;
+    constexpr int BK = 8 * EPC;
+
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * 128 * 128];
+
+    const int nwg = gridDim.x;
+    int sid;
+    {
+        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    int bm, bn;
+    if (g.lower_only) {
+        bm = (int)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= sid) ++bm;
+        while ((int64_t)bm * (bm + 1) / 2 > sid) --bm;
+        bn = sid - (int)((int64_t)bm * (bm + 1) / 2);
+    } else {
+        bm = sid / g.tiles_n;
+        bn = sid - bm * g.tiles_n;
+    }
+    const int64_t m0 = (int64_t)bm * 128, n0 = (int64_t)bn * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- LDS-DMA assignment: wave w stages 8-row groups {w, w+4, w+8, w+12} of each operand ----
+    // lane l -> row 8*grp + (l>>3), LDS slot l&7, which must hold chunk (l&7) ^ ((row>>1)&7);
+    // (row>>1)&7 = (4*grp + (l>>4)) & 7 and grp&1 == wave&1 for all four groups.
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const T* Ag = g.A + (m0 + 8 * wave + srow) * g.lda + schunk * EPC;
+    const T* Bg = g.B + (n0 + 8 * wave + srow) * g.ldb + schunk * EPC;
+    auto stage = [&](int st, int kt) {
+        char* As = smem + st * 32768 + wave * 1024;
+        char* Bs = As + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_vp)(Ag + (int64_t)(32 * i) * g.lda + (int64_t)kt * BK),
+                                             (lds_vp)(As + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(Bg + (int64_t)(32 * i) * g.ldb + (int64_t)kt * BK),
+                                             (lds_vp)(Bs + i * 4096), 16, 0, 0);
+        }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4, fsw = fr >> 1;
+    const int aoff = (wr * 64 + fr) * 128;
+    const int boff = (wc * 64 + fr) * 128;
+    const int coff0 = ((fg ^ fsw) << 4), coff1 = (((4 + fg) ^ fsw) << 4);
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+
+    chunk_t a0[4], b0[4], a1[4], b1[4];
+    auto fread = [&](const char* As, int coff, chunk_t (&a)[4], chunk_t (&b)[4]) {
+        const char* Bs = As + 16384;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 2048 + coff);
+            b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 2048 + coff);
+        }
+    };
+    auto fmac = [&](const chunk_t (&a)[4], const chunk_t (&b)[4]) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+    };
+
+    stage(0, 0);
+    __syncthreads();            // hipcc drains vmcnt(0) before the barrier: stage 0 has landed
+    fread(smem, coff0, a0, b0);
+
+    int cur = 0;
+    for (int kt = 0; kt < g.ktiles; ++kt) {
+        const bool more = (kt + 1 < g.ktiles);
+        if (more) stage(cur ^ 1, kt + 1);          // stage cur^1 was last read before the previous barrier
+        const char* As = smem + cur * 32768;
+        fread(As, coff1, a1, b1);                  // next group's fragments fly under this group's MFMAs
+        fmac(a0, b0);
+        fmac(a1, b1);
+        __syncthreads();                           // vmcnt(0) + barrier: next stage complete and visible
+        cur ^= 1;
+        if (more) fread(smem + cur * 32768, coff0, a0, b0);
+    }
+
+    const T alpha = g.alpha, beta = g.beta;
+    if (beta != (T)0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T cv[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cv[r][j] = g.C[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
+            }
     }
 }
 
@@ -209,7 +366,8 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
     const double bytes = sizeof(T) * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
                                       (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     ProfScope ps(c, klass, flops, bytes);
-    hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, c->stream, g);
+    if (g_gemm_variant == 0) hipLaunchKernelGGL(gemm_nt_kernel_v0<T>, dim3((unsigned)tiles), dim3(256), 0, c->stream, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, c->stream, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -250,5 +408,57 @@ int test_mfma_launch(algp_ctx* c, int* mismatches_dev) {
 }
 template int test_mfma_launch<double>(algp_ctx*, int*);
 template int test_mfma_launch<float>(algp_ctx*, int*);
+
+
+// ---------------------------------------------------------------------------------------------
+// device-resident GEMM benchmark (A/B of kernel variants in one process, random operands)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void fill_random_kernel(T* p, int64_t n, unsigned seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = (T)((int)(x & 0xffff) - 32768) * (T)(1.0 / 32768.0);
+}
+
+template <typename T>
+int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lower_only, int beta_one, int reps,
+               double* ms_out) {
+    DevBuf a, b, cc;
+    int rc = ensure(c, a, sizeof(T) * m * k);
+    if (rc == ALGP_OK) rc = ensure(c, b, sizeof(T) * n * k);
+    if (rc == ALGP_OK) rc = ensure(c, cc, sizeof(T) * m * n);
+    if (rc != ALGP_OK) { hipFree(a.p); hipFree(b.p); hipFree(cc.p); return rc; }
+    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, c->stream, (T*)a.p, m * k, 1u);
+    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, c->stream, (T*)b.p, n * k, 2u);
+    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->stream, (T*)cc.p, m * n, 3u);
+    const int saved = g_gemm_variant;
+    g_gemm_variant = variant;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const T beta = beta_one ? (T)1 : (T)0;
+    for (int w = 0; w < 2 && rc == ALGP_OK; ++w)
+        rc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, m, n, k, (T)-1, (const T*)a.p, k, (const T*)b.p, k, beta,
+                               (const T*)cc.p, n, (T*)cc.p, n, lower_only);
+    hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps && rc == ALGP_OK; ++r)
+        rc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, m, n, k, (T)-1, (const T*)a.p, k, (const T*)b.p, k, beta,
+                               (const T*)cc.p, n, (T*)cc.p, n, lower_only);
+    hipEventRecord(e1, c->stream);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / (reps > 0 ? reps : 1);
+    g_gemm_variant = saved;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(a.p); hipFree(b.p); hipFree(cc.p);
+    c->dev_bytes -= (int64_t)(a.cap + b.cap + cc.cap);
+    return rc;
+}
+template int bench_gemm<double>(algp_ctx*, int64_t, int64_t, int64_t, int, int, int, int, double*);
+template int bench_gemm<float>(algp_ctx*, int64_t, int64_t, int64_t, int, int, int, int, double*);
 
 }  // namespace algp

@@ -144,20 +144,43 @@ template int trinv_diag_launch<double>(algp_ctx*, const double*, int64_t, double
 template int trinv_diag_launch<float>(algp_ctx*, const float*, int64_t, float*);
 
 // ---------------------------------------------------------------------------------------------
+// Two-level blocking.  The GEMM tile is 128 wide, but updating with K = 128 re-reads and re-writes
+// the whole trailing matrix (Cholesky) or re-streams all solved columns of X (TRSM) once per 128
+// columns: that is HBM-bound (16 flop/byte).  So blocks of WB = 512 columns are processed as a unit:
+// inside a block the 128-wide steps touch only the block's own columns; everything outside is
+// updated once per block with K = 512 (Cholesky) / produced by one n = 512 GEMM whose four column
+// tiles share each A row-panel through the XCD's L2 (TRSM).
+// ---------------------------------------------------------------------------------------------
+constexpr int WB = 512;
+
 template <typename T>
 int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
-    const int64_t nblk = npad / NB;
-    for (int64_t kb = 0; kb < nblk; ++kb) {
-        T* Akk = A + kb * NB * ld + kb * NB;
-        T* inv = invD + kb * NB * NB;
-        ALGP_TRY(potrf_diag_launch<T>(c, Akk, ld, inv, logdet_acc, info, kb * NB));
-        const int64_t mrem = npad - (kb + 1) * NB;
+    for (int64_t j0 = 0; j0 < npad; j0 += WB) {
+        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;       // block width (multiple of 128)
+        // ---- factor the block column [j0, j0+w) over all rows >= j0, 128 columns at a time ----
+        for (int64_t k0 = j0; k0 < j0 + w; k0 += NB) {
+            T* Akk = A + k0 * ld + k0;
+            T* inv = invD + (k0 / NB) * NB * NB;
+            ALGP_TRY(potrf_diag_launch<T>(c, Akk, ld, inv, logdet_acc, info, k0));
+            const int64_t mrem = npad - (k0 + NB);
+            if (mrem <= 0) continue;
+            T* P = A + (k0 + NB) * ld + k0;                          // rows below the diagonal block
+            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, NB, NB, (T)1, P, ld, inv, NB, (T)0, nullptr, 0,
+                                       P, ld, 0));
+            const int64_t wrem = j0 + w - (k0 + NB);                 // columns of this block still to do
+            if (wrem > 0) {
+                // A[k0+NB:, k0+NB : j0+w] -= P * P[0:wrem]^T   (K = 128, only inside the block column)
+                T* Cw = A + (k0 + NB) * ld + (k0 + NB);
+                ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, wrem, NB, (T)-1, P, ld, P, ld, (T)1, Cw, ld,
+                                           Cw, ld, 0));
+            }
+        }
+        // ---- trailing update with the whole block: A22 -= P_blk P_blk^T, K = w, lower tiles ----
+        const int64_t mrem = npad - (j0 + w);
         if (mrem > 0) {
-            T* P = A + (kb + 1) * NB * ld + kb * NB;          // panel below the diagonal block
-            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, NB, NB, (T)1, P, ld, inv, NB, (T)0, nullptr,
-                                       0, P, ld, 0));
-            T* A22 = A + (kb + 1) * NB * ld + (kb + 1) * NB;
-            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, mrem, NB, (T)-1, P, ld, P, ld, (T)1, A22, ld,
+            T* Pb = A + (j0 + w) * ld + j0;
+            T* A22 = A + (j0 + w) * ld + (j0 + w);
+            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, mrem, w, (T)-1, Pb, ld, Pb, ld, (T)1, A22, ld,
                                        A22, ld, 1));
         }
     }
@@ -166,18 +189,26 @@ int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doubl
 template int cholesky_blocked<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*);
 template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*);
 
-// X <- X L^-T, left-looking over column blocks: X_k = (X_k - X_{0:k} L_{k,0:k}^T) inv(L_kk)^T
+// X <- X L^-T, left-looking over 512-wide column blocks:
+//   X_J <- X_J - X_{0:J} L_{J,0:J}^T            (one GEMM, n = 512)
+//   inside J, 128 columns at a time: X_k <- (X_k - X_{J0:k} L_{k,J0:k}^T) inv(L_kk)^T
 template <typename T>
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                  int64_t ldl, const T* invD) {
-    const int64_t nblk = npad / NB;
-    for (int64_t kb = 0; kb < nblk; ++kb) {
-        T* Xk = X + kb * NB;
-        if (kb > 0)
-            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, kb * NB, (T)-1, X, ldx, L + kb * NB * ldl, ldl, (T)1, Xk,
-                                       ldx, Xk, ldx, 0));
-        ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + kb * NB * NB, NB, (T)0, nullptr, 0,
-                                   Xk, ldx, 0));
+    for (int64_t j0 = 0; j0 < npad; j0 += WB) {
+        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
+        T* Xj = X + j0;
+        if (j0 > 0)
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, w, j0, (T)-1, X, ldx, L + j0 * ldl, ldl, (T)1, Xj, ldx, Xj, ldx,
+                                       0));
+        for (int64_t k0 = j0; k0 < j0 + w; k0 += NB) {
+            T* Xk = X + k0;
+            if (k0 > j0)
+                ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, k0 - j0, (T)-1, Xj, ldx, L + k0 * ldl + j0, ldl, (T)1,
+                                           Xk, ldx, Xk, ldx, 0));
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, (T)0,
+                                       nullptr, 0, Xk, ldx, 0));
+        }
     }
     return ALGP_OK;
 }

@@ -1,0 +1,114 @@
+"""Candidate scoring sharded over the GPUs of one node (one process per GPU).
+
+The reference's greedy loop (agent.py:313-354) evaluates every candidate independently given
+the factor of the sampled set, so candidates shard embarrassingly:
+
+  * every rank holds the full factor L of the train set (factorised redundantly, no comms),
+  * rank r owns a contiguous slice of the candidate list and its V^T rows,
+  * per pick: local utilities -> ONE all-gather of the per-shard score vectors (RCCL over xGMI
+    when the backend is "nccl") -> the same first-max argmax on every rank (np.argmax semantics,
+    agent.py:349) -> every rank commits the global winner to its own shard.  A rank that does
+    not own the winner rebuilds the winner's row from the replicated factor
+    (algp_commit_pick), so no second collective is needed.
+
+``backend`` is any object with the `_hip.Context` scoring surface (scores / commit_pick / M);
+tests drive the same logic over gloo with a CPU stand-in backend.
+"""
+import numpy as np
+
+
+def partition(n_items, world_size):
+    """Contiguous, balanced split: the first (n % w) ranks get one extra item."""
+    base, rem = divmod(int(n_items), int(world_size))
+    counts = [base + (1 if r < rem else 0) for r in range(world_size)]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    return [(int(offs[r]), int(offs[r + 1])) for r in range(world_size)]
+
+
+class LocalComm(object):
+    """world_size == 1: no collective."""
+    rank, world_size = 0, 1
+    device_buffers = False
+
+    def all_gather(self, local, max_len):
+        return local[None, :]
+
+
+class TorchComm(object):
+    """torch.distributed all-gather.  With the "nccl" backend (= RCCL on ROCm) the score
+    vectors stay on the GPU: the library writes them straight into the send buffer."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        self.device_buffers = dist.get_backend() == 'nccl'
+        self.device = device
+        self._send = self._recv = None
+
+    def buffers(self, max_len):
+        t = self.torch
+        if self._send is None or self._send.numel() != max_len:
+            dev = self.device if self.device_buffers else 'cpu'
+            self._send = t.full((max_len,), float('-inf'), dtype=t.float64, device=dev)
+            self._recv = t.empty((self.world_size, max_len), dtype=t.float64, device=dev)
+        return self._send, self._recv
+
+    def all_gather(self, local, max_len):
+        send, recv = self.buffers(max_len)
+        if local is not None:                       # host scores (gloo)
+            send.fill_(float('-inf'))
+            send[:len(local)] = self.torch.from_numpy(np.ascontiguousarray(local))
+        self.dist.all_gather_into_tensor(recv.view(-1), send)
+        return recv.cpu().numpy() if self.device_buffers else recv.numpy()
+
+
+class ShardedGreedy(object):
+    """k greedy picks over a sharded candidate list.
+
+    all_cand_idx: the GLOBAL candidate list (pool indices) in rank order; rank r owns
+    all_cand_idx[lo_r:hi_r] per ``partition``.  The backend must already hold exactly that
+    slice as its candidates (set_candidates + solve_candidates done).
+    """
+
+    def __init__(self, backend, comm, all_cand_idx):
+        self.b = backend
+        self.comm = comm
+        self.all_idx = np.ascontiguousarray(all_cand_idx, dtype=np.int64)
+        self.parts = partition(len(self.all_idx), comm.world_size)
+        self.lo, self.hi = self.parts[comm.rank]
+        self.max_len = max(h - l for l, h in self.parts)
+        if getattr(backend, 'M', self.hi - self.lo) != self.hi - self.lo:
+            raise ValueError('backend holds %d candidates, this rank owns %d' % (backend.M, self.hi - self.lo))
+
+    def _gather_scores(self, criterion, static_std, mobile_std):
+        if self.comm.world_size == 1:
+            return self.b.scores(criterion, static_std, mobile_std)[None, :]
+        if self.comm.device_buffers:
+            send, _ = self.comm.buffers(self.max_len)
+            self.b.scores(criterion, static_std, mobile_std, out_device_ptr=send.data_ptr())
+            return self.comm.all_gather(None, self.max_len)
+        return self.comm.all_gather(self.b.scores(criterion, static_std, mobile_std), self.max_len)
+
+    def step(self, criterion, static_std, mobile_std):
+        """One pick: returns (pool index of the winner, its utility)."""
+        g = self._gather_scores(criterion, static_std, mobile_std)
+        best_v, best_pos = -np.inf, -1
+        for r, (lo, hi) in enumerate(self.parts):          # first maximum in global order
+            if hi > lo:
+                seg = g[r, :hi - lo]
+                j = int(np.argmax(seg))
+                if best_pos < 0 or seg[j] > best_v:
+                    best_v, best_pos = float(seg[j]), lo + j
+        winner = int(self.all_idx[best_pos])
+        self.b.commit_pick(winner, static_std, mobile_std)
+        return winner, best_v
+
+    def greedy(self, criterion, static_std, mobile_std, k):
+        picks, vals = [], []
+        for _ in range(k):
+            w, v = self.step(criterion, static_std, mobile_std)
+            picks.append(w)
+            vals.append(v)
+        return picks, vals

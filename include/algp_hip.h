@@ -160,6 +160,10 @@ int algp_trsm_right_lt(algp_ctx* ctx, const void* L, int64_t n, const void* B, i
 /* MFMA fragment-layout probe: runs one 16x16x4 MFMA per dtype on exact integer operands and
  * returns the number of mismatching outputs (0 expected).                                      */
 int algp_selftest_mfma(algp_ctx* ctx, int* mismatches);
+/* device-resident GEMM timing on pseudo-random operands (no host traffic): average ms per launch
+ * of D = C - A B^T (beta_one) or D = -A B^T, m x n x k, kernel variant 0|1, lower tiles only or all. */
+int algp_bench_gemm(algp_ctx* ctx, int64_t m, int64_t n, int64_t k, int variant, int lower_only,
+                    int beta_one, int reps, double* ms_per_launch);
 
 /* ---- resident-buffer access for benchmarks / multi-GPU plumbing --------------------------- */
 int algp_sync(algp_ctx* ctx);
