@@ -42,6 +42,7 @@ SIGNATURES = {
     'algp_get_alpha': (C.c_int, [_c_ctx, C.c_void_p]),
     'algp_get_factor': (C.c_int, [_c_ctx, C.c_void_p]),
     'algp_get_mll': (C.c_int, [_c_ctx, _dblp]),
+    'algp_get_mll_grad': (C.c_int, [_c_ctx, _dblp]),
     'algp_set_candidates': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_int, C.c_void_p]),
     'algp_solve_candidates': (C.c_int, [_c_ctx]),
     'algp_get_posterior': (C.c_int, [_c_ctx, C.c_void_p, C.c_void_p]),
@@ -214,6 +215,12 @@ class Context(object):
 
     def mll(self):
         return self._get_double(self.lib.algp_get_mll)
+
+    def mll_grad(self):
+        """d MLL / d (log_lengthscale[D], log_outputscale, log_noise); not divided by N."""
+        g = np.empty(self.D + 2, dtype=np.float64)
+        self._check(self.lib.algp_get_mll_grad(self.h, g.ctypes.data_as(_dblp)))
+        return g
 
     def alpha(self):
         out = np.empty(self.N, dtype=self.dtype)

@@ -1,0 +1,325 @@
+"""Active-learning agent with the reference's `Agent` surface (reference agent.py:12-518); the
+GP arithmetic of every planning step runs in libalgp_hip.so.
+
+Hot-path methods (device):
+  _post_update  agent.py:89-90     pool coordinates go to the GPU; `cov_matrix` is built lazily
+  greedy        agent.py:295-356   one factorisation + one blocked solve + k rank-1 row appends
+                                    instead of k*M fresh slogdets
+  best_path     agent.py:358-403   one set entropy per path
+  predict       agent.py:289-293   -> utils.predictive_distribution
+  update_model  agent.py:84-87     -> GPR.fit (analytic MLL gradient on the device)
+Host bookkeeping (sample logs, sensor fusion, the IPP loop) follows the reference's behaviour and
+talks to the environment only through the reference's FieldEnv interface (env.X, env.test_X,
+env.num_samples, env.collect_samples, env.get_all_paths, ...), so a reference-style environment
+object drops in.  Path planning itself (env.py / map.py) is outside this package.
+"""
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from . import _hip
+from .models import GPR
+from .utils import compute_mae, find_equi_sample_path, find_shortest_path, predictive_distribution
+
+_CRIT = {'entropy': _hip.CRIT_ENTROPY, 'mutual_information': _hip.CRIT_MUTUAL_INFORMATION}
+
+
+def get_heading(prev, cur):
+    """Axis-aligned unit heading of the move prev -> cur; None if they coincide; a move with a row
+    component reports the row direction (reference graph_utils.py:15-25)."""
+    dr, dc = int(cur[0] - prev[0]), int(cur[1] - prev[1])
+    if dr == 0 and dc == 0:
+        return None
+    return (0, 1 if dc > 0 else -1) if dr == 0 else (1 if dr > 0 else -1, 0)
+
+
+class Agent(object):
+    def __init__(self, env, args, parent_agent=None, learn_likelihood_noise=True, mobile_std=None, static_std=None):
+        self.env = env
+        self.learn_likelihood_noise = learn_likelihood_noise
+        self._init_model(args)
+        self.static_std = args.static_std if static_std is None else static_std
+        self.mobile_std = 10 * self.static_std if mobile_std is None else mobile_std      # agent.py:20
+        self.num_samples_per_batch = args.num_samples_per_batch
+        self.update_every = args.update_every
+        self.criterion = getattr(args, 'criterion_default', 'entropy')
+        self._cov_matrix = None
+        self._cov_matrix_user = False
+        self._pool_key = None
+        self.reset()
+        if parent_agent is None:
+            self._pre_train(num_samples=int(args.fraction_pretrain * self.env.num_samples))
+        else:
+            self.load_model(parent_agent)
+            self.static_data = deepcopy(parent_agent.static_data)
+            self.mobile_data = deepcopy(parent_agent.mobile_data)
+            self.collected = deepcopy(parent_agent.collected)
+
+    # ---- model plumbing (agent.py:34-45) --------------------------------------------------------
+    def _init_model(self, args):
+        self.gp = GPR(latent=args.latent, lr=args.lr, max_iterations=args.max_iterations,
+                      kernel_params={'type': args.kernel}, learn_likelihood_noise=self.learn_likelihood_noise,
+                      dtype=getattr(args, 'dtype', np.float64), device=getattr(args, 'device', 0))
+
+    def load_model(self, parent_agent):
+        self.gp.reset(parent_agent.gp.train_x, parent_agent.gp.train_y, parent_agent.gp.train_var)
+        self.gp.model.load_state_dict(parent_agent.gp.model.state_dict())
+
+    def save_model(self, filename):
+        torch.save({'state_dict': self.gp.model.state_dict()}, filename)
+
+    # ---- sample bookkeeping (agent.py:47-82) -----------------------------------------------------
+    def reset(self):
+        self.pose = (0, 0)
+        self.heading = (1, 0)
+        self.path = np.copy(self.pose).reshape(-1, 2)
+        self.collected = {'ind': [], 'std': [], 'y': []}
+        self.static_locations = np.empty((0, 2))
+        self.static_data = [[] for _ in range(self.env.num_samples)]
+        self.mobile_data = [[] for _ in range(self.env.num_samples)]
+
+    def _pre_train(self, num_samples):
+        print('====================================================')
+        print('--- Pretraining ---')
+        self.pilot_survey(num_samples, self.static_std)
+        self.update_model()
+
+    def pilot_survey(self, num_samples, std):
+        ind = np.random.permutation(self.env.num_samples)[:num_samples]
+        self._add_samples(ind, stds=[std] * num_samples)
+
+    def _add_samples(self, indices, stds):
+        ys = [None] * len(indices)
+        for k, (idx, sd) in enumerate(zip(indices, stds)):
+            if idx == -1:                                   # off-field cell on a path (agent.py:70-71)
+                continue
+            y = self.env.collect_samples(idx, sd)
+            ys[k] = y
+            (self.static_data if sd == self.static_std else self.mobile_data)[idx].append(y)
+        self.collected['ind'] += list(indices)
+        self.collected['std'] += list(stds)
+        self.collected['y'] += ys
+
+    # ---- fusion of repeated readings (agent.py:92-117) --------------------------------------------
+    def get_sampled_dataset(self):
+        ss, sm = self.static_std ** 2, self.mobile_std ** 2
+        idx, ys, vs = [], [], []
+        for i in range(self.env.num_samples):
+            s, m = self.static_data[i], self.mobile_data[i]
+            if s and m:
+                y = (sm * np.mean(s) + ss * np.mean(m)) / (sm + ss)
+                v = 1 / (1 / ss + 1 / sm)
+            elif s:
+                y, v = np.mean(s), ss
+            elif m:
+                y, v = np.mean(m), sm
+            else:
+                continue
+            idx.append(i)
+            ys.append(y)
+            vs.append(v)
+        return idx, np.array(ys), np.array(vs)
+
+    def _masks(self):
+        static = np.array([len(v) > 0 for v in self.static_data], dtype=bool)
+        mobile = np.array([len(v) > 0 for v in self.mobile_data], dtype=bool)
+        return static, mobile
+
+    def _fused_var(self, static, mobile):
+        """Noise variance of every sampled site given the masks (agent.py:298-307)."""
+        ss, sm = self.static_std ** 2, self.mobile_std ** 2
+        both = 1.0 / (1.0 / ss + 1.0 / sm)
+        return np.where(static & mobile, both, np.where(static, ss, sm))
+
+    # ---- model update (agent.py:84-90) ---------------------------------------------------------
+    def update_model(self):
+        indices, y, var = self.get_sampled_dataset()
+        self.gp.fit(self.env.X[indices], y, var)
+        self._pool_key = None                                     # fit re-used the device pool
+
+    def _post_update(self):
+        """agent.py:89-90 computes the dense n x n pool covariance on the host; here the pool
+        coordinates are (re)loaded on the device and the dense matrix is only materialised if
+        somebody reads `cov_matrix`."""
+        self._cov_matrix = None
+        self._cov_matrix_user = False
+        self._pool_key = None
+
+    @property
+    def cov_matrix(self):
+        if self._cov_matrix is None:
+            self._cov_matrix = self.gp.cov_mat(x1=self.env.X, add_likelihood_var=True)
+        return self._cov_matrix
+
+    @cov_matrix.setter
+    def cov_matrix(self, value):
+        """Assigning a matrix makes greedy / best_path use exactly it (reference semantics)."""
+        self._cov_matrix = np.asarray(value)
+        self._cov_matrix_user = True
+        self._pool_key = None
+
+    def _load_pool(self):
+        c = self.gp.ctx
+        changed = self.gp.sync_hypers()
+        key = ('cov', id(self._cov_matrix)) if self._cov_matrix_user else ('x', id(self.env.X))
+        if changed or key != self._pool_key or getattr(c, '_pool_owner', None) is not self:
+            if self._cov_matrix_user:
+                c.set_pool_cov(self._cov_matrix)
+            else:
+                c.set_pool(self.env.X)
+            self._pool_key = key
+            c._pool_owner = self
+        return c
+
+    # ---- planning steps ---------------------------------------------------------------------------
+    def _setup_ipp(self, criterion, update=False):
+        self.criterion = criterion
+        self._post_update()
+
+    def predict(self, x=None, return_var=False, return_cov=False, return_mi=False):
+        x = self.env.test_X if x is None else x
+        ind, y, var = self.get_sampled_dataset()
+        self._pool_key = None                                       # predictive_distribution reloads the pool
+        return predictive_distribution(self.gp, self.env.X[ind], y, x, var, return_var=return_var,
+                                       return_cov=return_cov, return_mi=return_mi)
+
+    def greedy(self, num_samples):
+        """k most informative static sampling sites, greedily (agent.py:295-356)."""
+        c = self._load_pool()
+        static, mobile = self._masks()
+        sampled = static | mobile
+        A = np.where(sampled)[0]
+        c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
+        c.factorize()
+        c.set_candidates(np.where(~static)[0], prior_includes_noise=True)
+        c.solve_candidates()
+        picks = c.greedy(_CRIT[self.criterion], self.static_std, self.mobile_std, int(num_samples))
+        return [int(p) for p in picks]
+
+    def best_path(self, paths_mobile_indices, static_indices):
+        """Index of the most informative path (agent.py:358-403)."""
+        if len(paths_mobile_indices) == 1:
+            return 0
+        c = self._load_pool()
+        n = self.env.num_samples
+        static, mobile0 = self._masks()
+        static = static.copy()
+        static[static_indices] = True
+        utilities = []
+        for path in paths_mobile_indices:
+            mobile = mobile0.copy()
+            mobile[path] = True
+            sampled = static | mobile
+            A = np.where(sampled)[0]
+            var = self._fused_var(static[A], mobile[A])
+            ut = c.set_entropy(A, var)
+            if self.criterion == 'mutual_information':
+                ut += c.set_entropy(np.where(~sampled)[0])            # H(C_AbarAbar), no measurement noise
+                var_all = np.zeros(n)
+                var_all[A] = var
+                ut -= c.set_entropy(np.arange(n), var_all)
+            utilities.append(ut)
+        return int(np.argmax(utilities))
+
+    # ---- the loops (agent.py:125-287, 475-518): host orchestration around the steps above -------------
+    def get_samples_sequence_from_path(self, path, waypoints):
+        indices, stds = [], []
+        taken = [False] * len(waypoints)
+        for loc in path:
+            loc = tuple(loc)
+            gi = self.env.map_pose_to_gp_index_matrix[loc]
+            if gi is None:
+                indices.append(-1)
+                stds.append(-1)
+                continue
+            indices.append(gi)
+            if loc in waypoints and not taken[waypoints.index(loc)]:
+                taken[waypoints.index(loc)] = True
+                stds.append(self.static_std)
+            else:
+                stds.append(self.mobile_std)
+        return indices, stds
+
+    def _follow(self, checkpoints, waypoints):
+        nxt = np.stack(self.env.get_path_from_checkpoints(checkpoints))[1:]
+        ind, stds = self.get_samples_sequence_from_path(nxt, waypoints)
+        self.path = np.concatenate([self.path, nxt], axis=0).astype(int)
+        self.pose = tuple(self.path[-1])
+        self.heading = get_heading(self.path[-2], self.path[-1])
+        return ind, stds
+
+    def _choose(self, strategy, paths_indices, paths_cost, static_indices):
+        if strategy == 'Shortest':
+            return find_shortest_path(paths_cost)
+        best = self.best_path(paths_indices, static_indices)
+        return find_equi_sample_path(paths_indices, best) if strategy == 'Equi-Sample' else best
+
+    def run_ipp(self, render=False, num_runs=10, criterion='entropy', update=False, slack=0, strategy='MaxEnt',
+                disp=True):
+        assert strategy in ['MaxEnt', 'Shortest', 'Equi-Sample'], 'Unknown strategy!!'
+        assert criterion in ['entropy', 'mutual_information'], 'Unknown criterion!!'
+        self._setup_ipp(criterion, update)
+        test_error, pred, var, error = [], None, None, None
+        for i in range(num_runs):
+            t_run = time.time()
+            new_idx = self.greedy(self.num_samples_per_batch)
+            waypoints = [tuple(self.env.gp_index_to_map_pose(g)) for g in new_idx]
+            nxt_static = np.stack(waypoints)
+            self.static_locations = np.concatenate([self.static_locations, nxt_static]).astype(int)
+            ub = self.env.get_heuristic_cost(self.pose, self.heading, waypoints)
+            checkpoints, paths_idx, paths_cost = self.env.get_all_paths(self.pose, self.heading, waypoints, ub, slack)
+            best = self._choose(strategy, paths_idx, paths_cost, new_idx)
+            ind, stds = self._follow(checkpoints[best], waypoints)
+            if render:
+                self.predict(self.env.all_x)
+                self.env.render(checkpoints[best], self.path, nxt_static, self.static_locations)
+            self._add_samples(ind, stds)
+            if update and (i + 1) % self.update_every == 0:
+                self.update_model()
+                self._post_update()
+            pred, var = self.predict(return_var=True)
+            error = compute_mae(self.env.test_Y, pred)
+            test_error.append(error)
+            if disp:
+                print('Run {}/{}: {} feasible paths, test ERROR {:.4f}, predictive variance max {:.3f} min {:.3f} '
+                      'mean {:.3f}, {:.3f}s'.format(i + 1, num_runs, len(paths_idx), error, var.max(), var.min(),
+                                                    var.mean(), time.time() - t_run))
+        print('Strategy: {:s}  final test ERROR: {}'.format(strategy, error))
+        return {'mean': pred, 'error': test_error}
+
+    def run_greedy_ipp(self, num_runs=10, criterion='entropy', strategy='MaxEnt', disp=True):
+        self._setup_ipp(criterion)
+        for i in range(num_runs):
+            new_idx = self.greedy(self.num_samples_per_batch)
+            waypoints = [tuple(self.env.gp_index_to_map_pose(g)) for g in new_idx]
+            self.static_locations = np.concatenate([self.static_locations, np.stack(waypoints)]).astype(int)
+            costs, seq = self.env.map.nearest_waypoint_path_cost(self.pose, self.heading, waypoints, return_seq=True)
+            for j in range(len(seq)):
+                checkpoints, paths_idx, paths_cost = self.env.get_all_paths(self.pose, self.heading, [waypoints[seq[j]]],
+                                                                            costs[j], slack=0)
+                assert costs[j] == paths_cost[0], 'path costs do not match'
+                best = self._choose(strategy, paths_idx, paths_cost, [new_idx[seq[j]]])
+                ind, stds = self._follow(checkpoints[best], waypoints)
+                self._add_samples(ind, stds)
+        pred, var = self.predict(return_var=True)
+        error = compute_mae(self.env.test_Y, pred)
+        print('Strategy: {:s}  final test ERROR: {:.4f}'.format(strategy, error))
+        return {'mean': pred, 'error': [error]}
+
+    def prediction_vs_distance(self, test_every, num_runs):
+        errors, mis, mean_vars, mu = [], [], [], None
+        for r in range(1, num_runs + 1):
+            count = r * test_every
+            inds = np.array(self.collected['ind'][:count])
+            ok = inds != -1
+            x = self.env.X[inds[ok].astype(int)]
+            var = np.array(self.collected['std'])[:count][ok].astype(float) ** 2
+            y = np.array(self.collected['y'])[:count][ok].astype(float)
+            self._pool_key = None
+            mu, cov, mi = predictive_distribution(self.gp, x, y, self.env.test_X, var, return_mi=True, return_cov=True)
+            errors.append(compute_mae(self.env.test_Y, mu))
+            mis.append(mi)
+            mean_vars.append(np.diag(cov).mean())
+        return {'mean': mu, 'error': errors, 'mi': mis, 'mean_var': mean_vars}

@@ -720,6 +720,31 @@ struct Impl {
         return ALGP_OK;
     }
 
+    static int mll_grad(algp_ctx* c, double* grad_out) {
+        if (!c->factored) return fail(c, ALGP_ERR_STATE, "get_mll_grad: call algp_factorize first");
+        if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "get_mll_grad needs a coordinate pool");
+        const int64_t N = c->N, Npad = c->Npad;
+        const int D = c->hyp.D, DP = c->hyp.DP;
+        ALGP_TRY(ensure(c, c->auxW, sizeof(T) * Npad * Npad));
+        ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Npad * Npad));
+        // X = I L^-T = L^-T ;  S^-1 = X X^T (lower tiles)
+        ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), Npad, Npad));
+        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), Npad, Npad, p(c->invD)));
+        ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, Npad, Npad, Npad, (T)1, p(c->auxW), Npad, p(c->auxW), Npad,
+                                   (T)0, nullptr, 0, p(c->auxA), Npad, 1));
+        double* sc = (double*)c->scal.p + 16;             // slots 16..27: os, trace, ls[0..8)
+        ALGP_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 12, c->stream));
+        ALGP_TRY(mll_grad_launch<T>(c, p(c->auxA), Npad, N, (const T*)c->Xs.p, DP, (const int64_t*)c->Aidx.p,
+                                    (const T*)c->alpha.p, c->hyp.kernel, (T)c->hyp.outputscale, sc));
+        double h[12];
+        ALGP_HIP(hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        for (int d = 0; d < D; ++d) grad_out[d] = 0.5 * h[2 + d];
+        grad_out[D] = 0.5 * h[0];
+        grad_out[D + 1] = 0.5 * c->hyp.noise * h[1];
+        return ALGP_OK;
+    }
+
     static int get_alpha(algp_ctx* c, void* out) {
         if (!c->factored) return fail(c, ALGP_ERR_STATE, "get_alpha: call algp_factorize first");
         ALGP_HIP(hipMemcpyAsync(out, c->alpha.p, sizeof(T) * c->N, hipMemcpyDeviceToHost, c->stream));
@@ -892,6 +917,11 @@ int algp_get_mll(algp_ctx* c, double* mll) {
     if (!c->factored || !mll) return fail(c, ALGP_ERR_STATE, "get_mll: call algp_factorize first");
     *mll = -0.5 * c->yalpha - 0.5 * c->logdet - 0.5 * (double)c->N * 1.8378770664093453;
     return ALGP_OK;
+}
+int algp_get_mll_grad(algp_ctx* c, double* grad) {
+    CHECK_CTX(c);
+    if (!grad) return fail(c, ALGP_ERR_BAD_ARG, "get_mll_grad: bad arguments");
+    FINISH(c, DISPATCH(c, mll_grad(c, grad)));
 }
 int algp_get_alpha(algp_ctx* c, void* out) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_alpha(c, out))); }
 int algp_get_factor(algp_ctx* c, void* out) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_factor(c, out))); }

@@ -1,0 +1,97 @@
+// fit.hip -- gradient of the exact-GP marginal log likelihood w.r.t. the D+2 log hyper-parameters
+// (what gpytorch's autograd computes inside the reference's fit loop, models.py:145-158).
+//
+//   MLL = -1/2 y0' S^-1 y0 - 1/2 log det S - N/2 log 2pi,   S = K + diag(var) + sigma_n^2 I
+//   dMLL/dtheta = 1/2 tr(W dS/dtheta),  W = alpha alpha' - S^-1
+//   dS/dlog os = K ; dS/dlog ls_d = K .* u_d^2 (RBF) | 3 os e^{-a} u_d^2 (Matern-1.5), u_d = (x_d-x'_d)/ls_d
+//   dS/dlog sigma_n^2 = sigma_n^2 I
+// S^-1 = X X' with X = L^-T (one blocked TRSM of the identity + one lower SYRK on the MFMA GEMM);
+// the pairwise reduction below then streams the lower triangle of S^-1 once (HBM-bound, s*N^2/2
+// bytes) while K and u_d are recomputed from the scaled coordinates.
+#include "common.h"
+
+namespace algp {
+
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void mll_grad_kernel(const T* Sinv, int64_t ld, int64_t N, const T* Xs,
+                                                       const int64_t* aidx, const T* alpha, int kernel, T os,
+                                                       double* out /* [0]=os, [1]=noise trace, [2..2+DP) = ls */) {
+    // one workgroup = a 64-row x 64-col tile of the lower triangle (tiles with bj > bi are skipped)
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // tx: column, ty: 4 row groups of 16
+    const int64_t j = (int64_t)bj * 64 + tx;
+    double g_os = 0, g_tr = 0, g_ls[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) g_ls[d] = 0;
+    if (j < N) {
+        T xj[DP];
+        const int64_t pj = aidx[j];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xj[d] = Xs[pj * DP + d];
+        const T aj = alpha[j];
+        for (int rr = 0; rr < 16; ++rr) {
+            const int64_t i = (int64_t)bi * 64 + ty * 16 + rr;
+            if (i >= N || j > i) continue;
+            const int64_t pi = aidx[i];
+            T u2[DP], r2 = (T)0;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const T df = Xs[pi * DP + d] - xj[d];
+                u2[d] = df * df;
+                r2 += u2[d];
+            }
+            const T w = alpha[i] * aj - Sinv[i * ld + j];
+            const double m = (i == j) ? 1.0 : 2.0;               // symmetric: off-diagonal pairs count twice
+            T kv, dk;                                            // dk * u_d^2 = dK/dlog ls_d
+            if (kernel == ALGP_KERNEL_RBF) {
+                kv = os * exp((T)-0.5 * r2);
+                dk = kv;
+            } else {
+                const T a = sqrt(r2) * (T)1.7320508075688772;
+                const T e = exp(-a);
+                kv = os * ((T)1 + a) * e;
+                dk = (T)3 * os * e;
+            }
+            g_os += m * (double)(w * kv);
+            if (i == j) g_tr += (double)w;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) g_ls[d] += m * (double)(w * dk * u2[d]);
+        }
+    }
+    // block reduction: wave shuffles, then one atomic per wave and quantity
+    auto wsum = [](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        return v;
+    };
+    g_os = wsum(g_os);
+    g_tr = wsum(g_tr);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) g_ls[d] = wsum(g_ls[d]);
+    if (tx == 0) {
+        atomicAdd(out + 0, g_os);
+        atomicAdd(out + 1, g_tr);
+#pragma unroll
+        for (int d = 0; d < DP; ++d) atomicAdd(out + 2 + d, g_ls[d]);
+    }
+}
+
+template <typename T>
+int mll_grad_launch(algp_ctx* c, const T* Sinv, int64_t ld, int64_t N, const T* Xs, int DP, const int64_t* aidx,
+                    const T* alpha, int kernel, T os, double* out_dev) {
+    if (N <= 0) return ALGP_OK;
+    const unsigned nb = (unsigned)((N + 63) / 64);
+    ProfScope ps(c, ALGP_PROF_KMAT, 0.5 * (double)N * N * (3.0 * DP + 8.0), sizeof(T) * 0.5 * (double)N * N);
+    dim3 grid(nb, nb), blk(256);
+    if (DP == 2) hipLaunchKernelGGL((mll_grad_kernel<T, 2>), grid, blk, 0, c->stream, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
+    else if (DP == 4) hipLaunchKernelGGL((mll_grad_kernel<T, 4>), grid, blk, 0, c->stream, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
+    else hipLaunchKernelGGL((mll_grad_kernel<T, 8>), grid, blk, 0, c->stream, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int mll_grad_launch<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, int, const int64_t*,
+                                     const double*, int, double, double*);
+template int mll_grad_launch<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, int, const int64_t*,
+                                    const float*, int, float, double*);
+
+}  // namespace algp

@@ -101,6 +101,10 @@ int algp_get_entropy(algp_ctx* ctx, double* H);              /* N*CONST + 1/2 lo
 int algp_get_alpha(algp_ctx* ctx, void* alpha_out);          /* N values                         */
 int algp_get_factor(algp_ctx* ctx, void* L_out);             /* N x N lower, zeros above         */
 int algp_get_mll(algp_ctx* ctx, double* mll);                /* -1/2 y0'alpha - 1/2 logdet - N/2 log 2pi */
+/* ---- f2: gradient of the MLL for GPR.fit (models.py:137-159; the loss there is -MLL/N) ------
+ * grad_out[D+2] = d MLL / d (log_lengthscale[0..D), log_outputscale, log_noise), NOT divided by N.
+ * Needs a coordinate pool and a current factorisation.                                          */
+int algp_get_mll_grad(algp_ctx* ctx, double* grad_out);
 
 /* ---- candidates / test points: predictive_distribution (utils.py:293-319), greedy's pool ---
  * idx[M] pool indices.  A candidate that is itself in the train set (a mobile-sampled site,
