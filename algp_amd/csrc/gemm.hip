@@ -26,37 +26,11 @@
 //   16-byte aligned base pointers.  In-place use (D aliasing A) is safe iff n == 128: a
 //   workgroup then reads exactly the rows it later overwrites and finishes reading first.
 #include "common.h"
+#include "mfma.h"
 
 namespace algp {
 
 int g_gemm_variant = 0;   // 0 = register-staged (default), 1 = LDS-DMA staging (kept for A/B benchmarking)
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-template <typename T>
-struct MF;
-template <>
-struct MF<double> {
-    using acc_t = v4d;
-    using chunk_t = v2d;
-    static constexpr int EPC = 2;
-    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
-        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-template <>
-struct MF<float> {
-    using acc_t = v4f;
-    using chunk_t = v4f;
-    static constexpr int EPC = 4;
-    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
-};
 
 template <typename T>
 struct GemmArgs {

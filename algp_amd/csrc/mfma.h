@@ -1,0 +1,39 @@
+// MFMA traits shared by the GEMM and the diagonal-block kernel.
+//   fp64: v_mfma_f64_16x16x4_f64   C/D: row = (lane>>4) + 4*reg, col = lane&15
+//   fp32: v_mfma_f32_16x16x4_f32   C/D: row = (lane>>4)*4 + reg, col = lane&15
+// A operand: one scalar per lane, A[i = lane&15][k = lane>>4]; B: B[k = lane>>4][j = lane&15].
+// Accumulators must live in arch VGPRs for fp64 (AGPR accumulators run at half rate, see
+// profiles/r01_mfma_rate_microbench.txt): keep kernels at <= 256 registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace algp {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct MF;
+template <>
+struct MF<double> {
+    using acc_t = v4d;
+    using chunk_t = v2d;
+    static constexpr int EPC = 2;
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct MF<float> {
+    using acc_t = v4f;
+    using chunk_t = v4f;
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+}  // namespace algp

@@ -11,121 +11,282 @@
 // Triangular solves never substitute element by element: every diagonal block is applied through
 // its explicit 128 x 128 inverse (a GEMM), which keeps all O(n^2 m) work on the matrix cores.
 #include "common.h"
+#include "mfma.h"
 #include "vecops.h"
 
 namespace algp {
 
+// Diagnostic builds only (tools/potrf_stamp.hip): cycle stamps of thread 0 at phase boundaries.
+#ifdef ALGP_POTRF_STAMPS
+__device__ unsigned long long g_potrf_stamps[64];
+#define ALGP_STAMP(k) do { if (threadIdx.x == 0) g_potrf_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ALGP_STAMP(k) do { } while (0)
+#endif
+
+// 1/x and 1/sqrt(x) from the hardware seed + Newton steps (a full IEEE fp64 divide / sqrt costs
+// several hundred cycles and sits on the critical path of every pivot column)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+__device__ __forceinline__ float fast_rsqrt(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    return r * (1.5f - 0.5f * x * r * r);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Diagonal block: factor + invert a 128 x 128 SPD block inside one workgroup's LDS.
-//   S[128][129] holds the block (padding 1 element/row: column walks hit distinct banks).
-//   Phase 1 (LDL-style, one barrier per column): for column j with pivot d_j = S[j][j],
-//            S[i][k] -= S[i][j] * S[k][j] / d_j  for j < k <= i.  Columns stay unscaled.
-//   Phase 2: L[i][j] = S[i][j] / sqrt(d_j), L[j][j] = sqrt(d_j).
-//   Phase 3: X = L^-1 row by row; X[i][j] (j < i) is kept transposed in the (free) strict upper
-//            triangle S[j][i]; each of the 128 columns is reduced by 8 lanes.
+// Diagonal block: factor + invert a 128 x 128 SPD block inside one 256-thread workgroup's LDS.
+//   S[128][129] holds the block (one element of padding per row: column walks hit distinct banks).
+//   Factor, 16 columns at a time (8 panels):
+//     - LDL-style column sweep restricted to the panel: for column j with pivot d_j = S[j][j],
+//       S[i][k] -= S[i][j] S[k][j] / d_j for j < k < panel end, k <= i   (one barrier per column,
+//       but only 16 columns wide and 4 waves deep);
+//     - scale the panel: L[i][c] = S[i][c] / sqrt(d_c);
+//     - rank-16 update of everything right of the panel with 4 x 4 register tiles (one barrier).
+//   Inverse X = L^-1 by 16 x 16 blocks: the 8 diagonal blocks by per-column substitution (no
+//   barrier), then block row I: T = sum_K L_IK X_KJ for all J < I, X_IJ = -X_II T (two barriers).
+//   X[a][b] (a > b) is kept transposed in the free strict upper triangle, S[b][a]; X[a][a] = dinv[a].
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool FACTOR>
-__global__ __launch_bounds__(1024) void potrf_diag_kernel(T* A, int64_t lda, T* inv_out, double* logdet_acc,
-                                                           int* info, int64_t block_row0) {
+__global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* inv_out, double* logdet_acc,
+                                                          int* info, int64_t block_row0) {
     __shared__ T S[128 * 129];
     __shared__ T dd[128];
     __shared__ T dinv[128];
-    __shared__ double red[16];
+    __shared__ double red[4];
+    __shared__ T prow[2 * 18];
     __shared__ int bad;
     const int tid = threadIdx.x;
+    ALGP_STAMP(0);
     if (tid == 0) bad = 0;
-    for (int e = tid; e < 128 * 128; e += 1024) {
-        const int i = e >> 7, j = e & 127;
-        S[i * 129 + j] = A[(int64_t)i * lda + j];
-    }
-    __syncthreads();
-
-    if (FACTOR) {
-    const int ty = tid >> 5, tx = tid & 31;
-    for (int j = 0; j < 128; ++j) {
-        const T d = S[j * 129 + j];
-        if (tid == 0) {
-            dd[j] = d;
-            if (!(d > (T)0) && bad == 0) bad = j + 1;
-        }
-        const T rd = (T)1 / d;
+    {
+        // block load: 16-byte vectors, 8 loads in flight per thread (a load-per-iteration loop
+        // serialises 64 memory round trips and alone costs >100 us)
+        constexpr int VEC = 16 / sizeof(T);
+        typedef T vec_t __attribute__((ext_vector_type(VEC)));
+        constexpr int VPR = 128 / VEC;                  // vectors per row
+        constexpr int NV = 128 * VPR / 256;             // vectors per thread
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int i = j + 1 + ty + 32 * a;
-            if (i < 128) {
-                const T ci = S[i * 129 + j] * rd;
+        for (int b0 = 0; b0 < NV; b0 += 8) {
+            vec_t tmp[8];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int k = j + 1 + tx + 32 * b;
-                    if (k <= i) S[i * 129 + k] -= ci * S[k * 129 + j];
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int v = tid + 256 * (b0 + u);
+                tmp[u] = *reinterpret_cast<const vec_t*>(A + (int64_t)(v / VPR) * lda + (v % VPR) * VEC);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = tid + 256 * (b0 + u);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) S[(v / VPR) * 129 + (v % VPR) * VEC + e] = tmp[u][e];
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
+    ALGP_STAMP(1);
 
-    // scale columns, take sqrt of pivots, accumulate log det
-    if (tid < 128) {
-        const T d = dd[tid];
-        const T s = sqrt(d);
-        dinv[tid] = (T)1 / s;
-    }
-    __syncthreads();
-    for (int e = tid; e < 128 * 128; e += 1024) {
-        const int i = e >> 7, j = e & 127;
-        if (j < i) S[i * 129 + j] *= dinv[j];
-        else if (j == i) S[i * 129 + i] = sqrt(dd[i]);
-    }
-    {
-        double v = (tid < 128) ? log((double)dd[tid]) : 0.0;
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((tid & 63) == 0) red[tid >> 6] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        atomicAdd(logdet_acc, red[0] + red[1]);
-        if (bad) atomicCAS(info, 0, (int)(block_row0 + bad));
-    }
-    // write L (lower incl. diagonal) back
-    for (int e = tid; e < 128 * 128; e += 1024) {
-        const int i = e >> 7, j = e & 127;
-        if (j <= i) A[(int64_t)i * lda + j] = S[i * 129 + j];
-    }
+    if (FACTOR) {
+        for (int k0 = 0; k0 < 128; k0 += 16) {
+            const int k1 = k0 + 16;
+            if (k0 == 0) ALGP_STAMP(2);
+            // ---- panel sweep: thread `rowid` owns row k0+rowid of the panel in registers; the pivot
+            //      row travels through a double-buffered LDS line: one barrier per column ----
+            const int rowid = tid;                       // threads >= 128-k0 idle here
+            const bool active = rowid < 128 - k0;
+            T a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = active ? S[(k0 + rowid) * 129 + k0 + c] : (T)0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                T* line = prow + (jj & 1) * 18;
+                // column jj of the diagonal 16 x 16 block (lower entries only: the upper triangle is
+                // never kept valid) is gathered from the threads that own those rows
+                if (rowid > jj && rowid < 16) line[rowid] = a[jj];
+                if (rowid == jj) {
+                    const T d = a[jj];
+                    line[16] = fast_rcp(d);
+                    dd[k0 + jj] = d;
+                    if (!(d > (T)0) && bad == 0) bad = k0 + jj + 1;
+                }
+                __syncthreads();
+                if (active && rowid > jj) {
+                    const T ci = a[jj] * line[16];
+#pragma unroll
+                    for (int c = jj + 1; c < 16; ++c) a[c] -= ci * line[c];
+                }
+            }
+            // ---- write the scaled panel back: L[i][c] = a[c] / sqrt(d_c) ----
+            __syncthreads();                             // dd[k0..k1) complete
+            if (tid < 16) dinv[k0 + tid] = fast_rsqrt(dd[k0 + tid]);
+            __syncthreads();
+            if (k0 == 0) ALGP_STAMP(3);
+            if (active) {
+                const int i = k0 + rowid;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (i > k0 + c) S[i * 129 + k0 + c] = a[c] * dinv[k0 + c];
+                    else if (i == k0 + c) S[i * 129 + i] = dd[i] * dinv[i];        // sqrt(d) = d / sqrt(d)
+                }
+            }
+            __syncthreads();
+            if (k0 == 0) ALGP_STAMP(4);
+            // ---- rank-16 update of everything right of the panel on the matrix cores: one 16 x 16
+            //      output tile = 4 MFMAs (K = 16); operands are 16 consecutive rows at one column
+            //      (row stride 129: conflict free); C tiles are read-modify-written in the C layout ----
+            const int r = 128 - k1;
+            if (r > 0) {
+                using F = MF<T>;
+                const int lane = tid & 63, wave = tid >> 6;
+                const int nb16 = r >> 4, ntile16 = nb16 * (nb16 + 1) / 2;
+                for (int t = wave; t < ntile16; t += 4) {
+                    int ti = 0;
+                    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                    const int tk = t - ti * (ti + 1) / 2;
+                    const int i0 = k1 + 16 * ti, c0 = k1 + 16 * tk;
+                    typename F::acc_t acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = (T)0;
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const T av = S[(i0 + (lane & 15)) * 129 + k0 + 4 * st + (lane >> 4)];
+                        const T bv = S[(c0 + (lane & 15)) * 129 + k0 + 4 * st + (lane >> 4)];
+                        acc = F::mfma(av, bv, acc);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        T* dst = S + (i0 + F::row_of(lane, q)) * 129 + c0 + (lane & 15);
+                        *dst -= acc[q];
+                    }
+                }
+                __syncthreads();
+                if (k0 == 0) ALGP_STAMP(5);
+            }
+        }
+        ALGP_STAMP(6);
+        {
+            double v = (tid < 128) ? log((double)dd[tid]) : 0.0;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((tid & 63) == 0) red[tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(logdet_acc, red[0] + red[1]);
+            if (bad) atomicCAS(info, 0, (int)(block_row0 + bad));
+        }
+        for (int e = tid; e < 128 * 128; e += 256) {
+            const int i = e >> 7, j = e & 127;
+            if (j <= i) A[(int64_t)i * lda + j] = S[i * 129 + j];
+        }
     } else {
         if (tid < 128) dinv[tid] = (T)1 / S[tid * 129 + tid];
     }
-    __syncthreads();   // everyone has read the lower part they need from S before the upper is reused
+    __syncthreads();
+    ALGP_STAMP(7);
 
-    // inverse, row by row: X[i][j] = -(sum_{k=j}^{i-1} L[i][k] X[k][j]) / L[i][i],  X[j][j] = dinv[j]
-    const int col = tid >> 3, part = tid & 7;
-    for (int i = 1; i < 128; ++i) {
-        T sum = (T)0;
-        if (col < i) {
-            for (int k = col + part; k < i; k += 8) {
-                const T xkj = (k == col) ? dinv[col] : S[col * 129 + k];
-                sum += S[i * 129 + k] * xkj;
+    // ---- inverse: diagonal 16 x 16 blocks, one column per thread, values kept in registers ----
+    if (tid < 128) {
+        const int base = (tid >> 4) * 16, c = tid & 15;
+        T x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = (T)0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i == c) x[i] = dinv[base + c];
+            if (i > c) {
+                T sum = (T)0;
+#pragma unroll
+                for (int k = 0; k < i; ++k)
+                    if (k >= c) sum += S[(base + i) * 129 + base + k] * x[k];
+                x[i] = -sum * dinv[base + i];
             }
         }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
-        sum += __shfl_xor(sum, 4, 64);
-        if (part == 0 && col < i) S[col * 129 + i] = -sum * dinv[i];
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i > c) S[(base + c) * 129 + base + i] = x[i];
     }
-    for (int e = tid; e < 128 * 128; e += 1024) {
+    __syncthreads();
+    ALGP_STAMP(8);
+    // ---- block rows 1..7 on the matrix cores.  For block (I, J), J < I:
+    //        T    = sum_{K=J}^{I-1} L_IK X_KJ      (A = L_IK rows r0+m; B[k][b] = X_KJ[k][b] = S[16J+b][16K+k])
+    //        X_IJ = -X_II T                          (A = X_II; B = T straight from the accumulator: for the
+    //                                                 k-step s the lane's register s IS row k of T in its column)
+    //      X_JJ / X_II are lower triangular with the diagonal in dinv and zeros above. ----
+    {
+        using F = MF<T>;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int li = lane & 15, lg = lane >> 4;
+        for (int I = 1; I < 8; ++I) {
+            const int r0 = 16 * I;
+            for (int J = wave; J < I; J += 4) {
+                const int b0 = 16 * J;
+                typename F::acc_t acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = (T)0;
+                // K = J: X_JJ[k][b] for k >= b only
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int k = 4 * st + lg;                        // row of X_JJ, b = li its column
+                    const T av = S[(r0 + li) * 129 + b0 + k];
+                    T bv = (T)0;
+                    if (k > li) bv = S[(b0 + li) * 129 + b0 + k];
+                    else if (k == li) bv = dinv[b0 + li];
+                    acc = F::mfma(av, bv, acc);
+                }
+                for (int K = J + 1; K < I; ++K) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const int k = 16 * K + 4 * st + lg;
+                        acc = F::mfma(S[(r0 + li) * 129 + k], S[(b0 + li) * 129 + k], acc);
+                    }
+                }
+                // X_IJ = -X_II T : k-step s pairs A[m'][k] with the accumulator register s, whose row is
+                // row_of(lane, s); A[m' = li][k] = X_II[li][k] = S[r0+k][r0+li] (k < li), dinv (k == li), 0 (k > li)
+                typename F::acc_t out;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[q] = (T)0;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int k = F::row_of(lane, st);
+                    T av = (T)0;
+                    if (k < li) av = S[(r0 + k) * 129 + r0 + li];
+                    else if (k == li) av = dinv[r0 + li];
+                    out = F::mfma(av, acc[st], out);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[(b0 + li) * 129 + r0 + F::row_of(lane, q)] = -out[q];
+            }
+            __syncthreads();
+            ALGP_STAMP(9 + I);
+        }
+    }
+    for (int e = tid; e < 128 * 128; e += 256) {
         const int i = e >> 7, j = e & 127;
         T v = (T)0;
         if (j < i) v = S[j * 129 + i];
         else if (j == i) v = dinv[i];
         inv_out[i * 128 + j] = v;
     }
+    ALGP_STAMP(17);
 }
 
 template <typename T>
 int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet_acc, int* info,
                       int64_t block_row0) {
     ProfScope ps(c, ALGP_PROF_POTRF_DIAG, 128.0 * 128.0 * 128.0, sizeof(T) * 3.0 * 128.0 * 128.0);
-    hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(1), dim3(1024), 0, c->stream, A, lda, inv_out, logdet_acc,
+    hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(1), dim3(256), 0, c->stream, A, lda, inv_out, logdet_acc,
                        info, block_row0);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -135,7 +296,7 @@ template int potrf_diag_launch<float>(algp_ctx*, float*, int64_t, float*, double
 
 template <typename T>
 int trinv_diag_launch(algp_ctx* c, const T* A, int64_t lda, T* inv_out) {
-    hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(1), dim3(1024), 0, c->stream, const_cast<T*>(A), lda, inv_out,
+    hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(1), dim3(256), 0, c->stream, const_cast<T*>(A), lda, inv_out,
                        (double*)nullptr, (int*)nullptr, (int64_t)0);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -229,11 +390,15 @@ __global__ __launch_bounds__(128) void diag_matvec_kernel(const T* inv, T* b) {
     const int t = threadIdx.x;
     xb[t] = b[t];
     __syncthreads();
+    // the inverse block is lower triangular with explicit zeros above: walk all 128 terms so the
+    // loads are independent and can be issued in batches (a data-dependent trip count serialises them)
     T s = (T)0;
     if (!TRANS) {
-        for (int k = 0; k <= t; ++k) s += inv[t * 128 + k] * xb[k];
+#pragma unroll 16
+        for (int k = 0; k < 128; ++k) s += inv[t * 128 + k] * xb[k];
     } else {
-        for (int k = t; k < 128; ++k) s += inv[k * 128 + t] * xb[k];
+#pragma unroll 16
+        for (int k = 0; k < 128; ++k) s += inv[k * 128 + t] * xb[k];
     }
     b[t] = s;
 }

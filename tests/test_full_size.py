@@ -1,0 +1,144 @@
+"""GPU tests at BASELINE.json's sizes through size-independent properties (the oracle cannot
+finish these in seconds), plus sampled direct checks against the oracle's formulas.
+
+  C2  2 000-point field, fp64: kernel build + Cholesky + posterior
+  C3 10 000-point field, fp32: blocked MFMA Cholesky
+  C4 10 000 train x 100 000 candidates (fp64), greedy scoring (also what bench.py times)
+"""
+import numpy as np
+import pytest
+
+from algp_amd import _hip
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def field(n_side_r, n_side_c, seed=1):
+    rng = np.random.RandomState(seed)
+    grid, y = O.generate_gaussian_data(n_side_r, n_side_c, k=5, rng=rng)
+    return grid.astype(np.float64), y, rng
+
+
+HYP = O.Hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+
+
+def test_c2_2000_points_fp64_against_oracle():
+    X, f, rng = field(50, 40)
+    n = len(X)
+    perm = rng.permutation(n)
+    A, T = np.sort(perm[:1600]), np.sort(perm[1600:])
+    var = rng.choice([0.01, 1.0], len(A))
+    y = np.maximum(f[A] + rng.standard_normal(len(A)) * np.sqrt(var), 0)
+    c = _hip.Context(np.float64)
+    c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+    K = c.kernel_matrix(X)                                    # a1 at full size: 2000 x 2000
+    assert np.max(np.abs(K - O.kernel_matrix(HYP, X))) < 1e-13
+    c.set_pool(X)
+    c.set_train(A, y, var)
+    c.factorize()
+    c.set_candidates(T, prior_includes_noise=False)
+    c.solve_candidates()
+    mu, pv = c.posterior()
+    ref = O.posterior_chol(HYP, X[A], y, X[T], var)           # 1600^3: still seconds on the CPU
+    assert np.max(np.abs(mu - ref['mu'])) / np.max(np.abs(ref['mu'])) < 1e-9     # north_star: 1e-5
+    assert np.max(np.abs(pv - ref['var'])) / np.max(np.abs(ref['var'])) < 1e-9
+    assert c.logdet() == pytest.approx(ref['logdet'], rel=1e-11)
+    L = c.factor()
+    S = O.kernel_matrix(HYP, X[A]) + np.diag(var) + HYP.noise * np.eye(len(A))
+    assert np.max(np.abs(L @ L.T - S)) < 1e-12
+    c.close()
+
+
+def test_c3_10000_points_fp32_cholesky_properties():
+    """fp32 Cholesky at N = 10 000: residual |L L^T v - S v| on random probes, log-det against the
+    fp64 context, posterior within 1e-3 of the fp64 context (north_star fp32 tolerance)."""
+    X, f, rng = field(100, 100)
+    n = len(X)
+    var = rng.choice([0.01, 1.0], n)
+    y = np.maximum(f + rng.standard_normal(n) * np.sqrt(var), 0)
+    T = np.arange(0, n, 97)
+    Xt = X[T] + 0.37
+    pool = np.vstack([X, Xt])
+    out = {}
+    for dt in (np.float32, np.float64):
+        c = _hip.Context(dt)
+        c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+        c.set_pool(pool)
+        c.set_train(np.arange(n), y, var)
+        c.factorize()
+        c.set_candidates(np.arange(n, n + len(T)), prior_includes_noise=False)
+        c.solve_candidates()
+        mu, pv = c.posterior()
+        out[dt] = (c.logdet(), mu.astype(np.float64), pv.astype(np.float64), c.factor() if dt == np.float32 else None)
+        c.close()
+    ld32, mu32, pv32, L32 = out[np.float32]
+    ld64, mu64, pv64, _ = out[np.float64]
+    assert ld32 == pytest.approx(ld64, rel=1e-4)
+    assert np.max(np.abs(mu32 - mu64)) / np.max(np.abs(mu64)) < 1e-3
+    assert np.max(np.abs(pv32 - pv64)) / np.max(np.abs(pv64)) < 1e-3
+    # residual through random probes (no 10k^3 product on the CPU): S v vs L (L^T v)
+    S = O.kernel_matrix(HYP, X) + np.diag(var) + HYP.noise * np.eye(n)
+    V = rng.standard_normal((n, 4))
+    L = L32.astype(np.float64)
+    res = L @ (L.T @ V) - S @ V
+    assert np.max(np.abs(res)) / np.max(np.abs(S @ V)) < 5e-6
+    assert np.all(np.diag(L32) > 0) and np.array_equal(np.triu(L32, 1), np.zeros_like(L32))
+
+
+def test_c4_10000_x_100000_scoring_properties():
+    """The bench workload.  Properties: (i) a sample of candidates against the direct formula
+    pv = C_jj - b' S^-1 b computed from the fp64 factor on the host, (ii) utilities are
+    monotone: every committed pick lowers every other candidate's utility, (iii) each pick is
+    the argmax of its utility vector and is never picked twice, (iv) the appended-row updates
+    equal a from-scratch refactorisation with the picks added to the train set."""
+    X, f, rng = field(100, 100)
+    N = len(X)
+    M = 100000
+    ii, jj = np.meshgrid(np.arange(400), np.arange(250), indexing='ij')
+    Xc = np.vstack([(ii.ravel() + 0.37) * 0.25, (jj.ravel() + 0.41) * 0.4]).T[:M]
+    pool = np.vstack([X, Xc])
+    is_static = rng.uniform(size=N) < 0.5
+    var = np.where(is_static, 0.01, 1.0)
+    y = np.maximum(f + rng.standard_normal(N) * np.sqrt(var), 0)
+    c = _hip.Context(np.float64)
+    c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+    c.set_pool(pool)
+    c.set_train(np.arange(N), y, var)
+    c.factorize()
+    cand = np.arange(N, N + M)
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    mu, pv = c.posterior()
+    # (i) sampled direct check
+    from scipy.linalg import solve_triangular
+    L = c.factor()
+    samp = rng.permutation(M)[:64]
+    B = O.kernel_matrix(HYP, X, Xc[samp])
+    V = solve_triangular(L, B, lower=True)
+    pv_want = HYP.outputscale + HYP.noise - np.sum(V * V, axis=0)
+    z = solve_triangular(L, y - y.mean(), lower=True)
+    assert np.max(np.abs(pv[samp] - pv_want)) < 1e-10
+    assert np.max(np.abs(mu[samp] - (y.mean() + V.T @ z))) < 1e-9
+    assert np.all(pv > 0) and np.all(pv <= HYP.outputscale + HYP.noise + 1e-12)
+    # (ii)-(iii)
+    picks, ut = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4, want_utilities=True)
+    assert len(set(picks.tolist())) == 4
+    for p in range(4):
+        assert cand[int(np.argmax(ut[p]))] == picks[p]
+        if p:
+            alive = np.isfinite(ut[p])
+            assert np.all(ut[p][alive] <= ut[p - 1][alive] + 1e-12)
+            assert np.isneginf(ut[p][picks[p - 1] - N])
+    assert np.allclose(ut[0], O.CONST + 0.5 * np.log(pv + 0.01), rtol=0, atol=1e-12)
+    # (iv) refactorise with the first 3 picks as static samples; utilities must match pick 4's
+    A2 = np.r_[np.arange(N), picks[:3]]
+    c.set_train(A2, np.r_[y, np.zeros(3)], np.r_[var, np.full(3, 0.01)])
+    c.factorize()
+    keep = np.setdiff1d(cand, picks[:3])
+    sub = keep[rng.permutation(len(keep))[:20000]]
+    c.set_candidates(np.sort(sub), prior_includes_noise=True)
+    c.solve_candidates()
+    s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    assert np.max(np.abs(s - ut[3][np.sort(sub) - N])) < 1e-9
+    c.close()
