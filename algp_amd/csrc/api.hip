@@ -73,13 +73,32 @@ void prof_begin(algp_ctx* c, int klass, double flops, double bytes) {
     c->prof[klass].flops += flops;
     c->prof[klass].bytes += bytes;
     c->prof[klass].launches += 1;
-    hipEventRecord(pe.a, c->stream);
+    hipEventRecord(pe.a, c->cur);
     c->pending.push_back(pe);
 }
 void prof_end(algp_ctx* c) {
     if (!c->prof_on) return;
     if (--prof_depth > 0) return;
-    hipEventRecord(c->pending.back().b, c->stream);
+    hipEventRecord(c->pending.back().b, c->cur);
+}
+static thread_local int span_index = -1;
+void prof_span_begin(algp_ctx* c, int klass, double flops, double bytes) {
+    if (!c->prof_on) return;
+    PendingEvent pe;
+    pe.a = get_event(c);
+    pe.b = get_event(c);
+    pe.klass = klass;
+    c->prof[klass].flops += flops;
+    c->prof[klass].bytes += bytes;
+    c->prof[klass].launches += 1;
+    hipEventRecord(pe.a, c->stream);
+    span_index = (int)c->pending.size();
+    c->pending.push_back(pe);
+}
+void prof_span_end(algp_ctx* c) {
+    if (!c->prof_on || span_index < 0) return;
+    hipEventRecord(c->pending[span_index].b, c->stream);
+    span_index = -1;
 }
 void prof_collect(algp_ctx* c) {
     for (auto& pe : c->pending) {
@@ -254,7 +273,10 @@ struct Impl {
         ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p, N, Npad, (const int64_t*)c->Aidx.p, N, Npad,
                                 (const T*)c->varA.p, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->L), Npad));
         double ld = 0;
-        ALGP_TRY(factor_resident(c, p(c->L), N, Npad, p(c->invD), SC_LOGDET, SC_INFO, &ld));
+        prof_span_begin(c, ALGP_PROF_CHOLESKY, (double)N * N * N / 3.0, sizeof(T) * (double)N * N);
+        int frc = factor_resident(c, p(c->L), N, Npad, p(c->invD), SC_LOGDET, SC_INFO, &ld);
+        prof_span_end(c);
+        ALGP_TRY(frc);
         c->logdet = ld;
         ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
         ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, Npad, p(c->invD), p(c->z)));
@@ -800,6 +822,8 @@ int algp_create(int device_id, int dtype, algp_ctx** out) {
     c->dtype = dtype;
     c->es = dtype == ALGP_F64 ? 8 : 4;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ALGP_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return ALGP_ERR_HIP; }
+    c->cur = c->stream;
     if (ensure(c, c->scal, sizeof(double) * SC_COUNT) != ALGP_OK) { hipStreamDestroy(c->stream); delete c; return ALGP_ERR_OOM; }
     hipMemsetAsync(c->scal.p, 0, sizeof(double) * SC_COUNT, c->stream);
     hipStreamSynchronize(c->stream);
@@ -818,6 +842,9 @@ void algp_destroy(algp_ctx* c) {
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    for (hipEvent_t e : c->sync_events) hipEventDestroy(e);
+    hipStreamSynchronize(c->stream2);
+    hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
 }

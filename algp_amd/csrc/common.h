@@ -50,7 +50,10 @@ struct algp_ctx {
     int device = 0;
     int dtype = ALGP_F64;
     size_t es = 8;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // main stream (all results are complete on it before an ABI call returns)
+    hipStream_t stream2 = nullptr;   // second stream (reserved for overlapped panel work; unused in round 1)
+    hipStream_t cur = nullptr;       // stream the launch helpers currently target
+    std::vector<hipEvent_t> sync_events;
     std::string err;
     int64_t pivot = 0;
     algp::Hypers hyp;
@@ -99,6 +102,9 @@ int ensure(algp_ctx* c, DevBuf& b, size_t bytes);
 void prof_begin(algp_ctx* c, int klass, double flops, double bytes);
 void prof_end(algp_ctx* c);
 void prof_collect(algp_ctx* c);
+// un-nested wall-time span on the main stream (e.g. a whole factorisation that overlaps two streams)
+void prof_span_begin(algp_ctx* c, int klass, double flops, double bytes);
+void prof_span_end(algp_ctx* c);
 
 #define ALGP_HIP(call)                                                                          \
     do {                                                                                        \

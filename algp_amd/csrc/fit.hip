@@ -83,9 +83,9 @@ int mll_grad_launch(algp_ctx* c, const T* Sinv, int64_t ld, int64_t N, const T* 
     const unsigned nb = (unsigned)((N + 63) / 64);
     ProfScope ps(c, ALGP_PROF_KMAT, 0.5 * (double)N * N * (3.0 * DP + 8.0), sizeof(T) * 0.5 * (double)N * N);
     dim3 grid(nb, nb), blk(256);
-    if (DP == 2) hipLaunchKernelGGL((mll_grad_kernel<T, 2>), grid, blk, 0, c->stream, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
-    else if (DP == 4) hipLaunchKernelGGL((mll_grad_kernel<T, 4>), grid, blk, 0, c->stream, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
-    else hipLaunchKernelGGL((mll_grad_kernel<T, 8>), grid, blk, 0, c->stream, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
+    if (DP == 2) hipLaunchKernelGGL((mll_grad_kernel<T, 2>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
+    else if (DP == 4) hipLaunchKernelGGL((mll_grad_kernel<T, 4>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
+    else hipLaunchKernelGGL((mll_grad_kernel<T, 8>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

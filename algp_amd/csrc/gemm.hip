@@ -30,6 +30,11 @@
 
 namespace algp {
 
+// Diagnostic builds only (tools/gemm_clock.hip): shader-clock / wall-clock ticks of wave 0 of each block.
+#ifdef ALGP_GEMM_CLOCK
+__device__ unsigned long long g_gemm_clk[2 * 8192];
+#endif
+
 int g_gemm_variant = 0;   // 0 = register-staged (default), 1 = LDS-DMA staging (kept for A/B benchmarking)
 
 template <typename T>
@@ -44,7 +49,7 @@ struct GemmArgs {
     int lower_only;
 };
 
-template <typename T>
+template <typename T, int VAR>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
@@ -116,8 +121,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
     gload(0);
     lstore(0);
     __syncthreads();
+#ifdef ALGP_GEMM_CLOCK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     int cur = 0;
+    if (VAR == 2) {
+        // fragment double-buffering: the ds_reads of the next 32-MFMA group fly under the current group
+        chunk_t a0[4], b0[4], a1[4], b1[4];
+        auto fread = [&](const char* As, int q, chunk_t (&a)[4], chunk_t (&b)[4]) {
+            const char* Bs = As + 16384;
+            const int coff = (((4 * q + fg) ^ fsw) << 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 2048 + coff);
+                b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 2048 + coff);
+            }
+        };
+        auto fmac = [&](const chunk_t (&a)[4], const chunk_t (&b)[4]) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+        };
+        fread(smem, 0, a0, b0);
+        for (int kt = 0; kt < g.ktiles; ++kt) {
+            const bool more = (kt + 1 < g.ktiles);
+            if (more) gload(kt + 1);
+            fread(smem + cur * 32768, 1, a1, b1);
+            fmac(a0, b0);
+            fmac(a1, b1);
+            if (more) lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+            if (more) fread(smem + cur * 32768, 0, a0, b0);
+        }
+    } else {
     for (int kt = 0; kt < g.ktiles; ++kt) {
         const bool more = (kt + 1 < g.ktiles);
         if (more) gload(kt + 1);
@@ -132,18 +173,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
                 a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 2048 + coff);
                 b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 2048 + coff);
             }
+            if (VAR == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int e = 0; e < EPC; ++e)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+            if (VAR == 3) __builtin_amdgcn_s_setprio(0);
         }
         if (more) lstore(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+    }
 
+#ifdef ALGP_GEMM_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_gemm_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_gemm_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
     // ---- epilogue: D = alpha*acc + beta*C; all C loads of a 16-row slab are issued before use ----
     const T alpha = g.alpha, beta = g.beta;
     if (beta != (T)0) {
@@ -340,8 +390,10 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
     const double bytes = sizeof(T) * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
                                       (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     ProfScope ps(c, klass, flops, bytes);
-    if (g_gemm_variant == 0) hipLaunchKernelGGL(gemm_nt_kernel_v0<T>, dim3((unsigned)tiles), dim3(256), 0, c->stream, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, c->stream, g);
+    if (g_gemm_variant == 0) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 0>), dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
+    else if (g_gemm_variant == 2) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 2>), dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
+    else if (g_gemm_variant == 3) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 3>), dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -376,7 +428,7 @@ __global__ void mfma_probe_kernel(int* mismatches) {
 
 template <typename T>
 int test_mfma_launch(algp_ctx* c, int* mismatches_dev) {
-    hipLaunchKernelGGL(mfma_probe_kernel<T>, dim3(1), dim3(64), 0, c->stream, mismatches_dev);
+    hipLaunchKernelGGL(mfma_probe_kernel<T>, dim3(1), dim3(64), 0, c->cur, mismatches_dev);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -404,9 +456,9 @@ int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lo
     if (rc == ALGP_OK) rc = ensure(c, b, sizeof(T) * n * k);
     if (rc == ALGP_OK) rc = ensure(c, cc, sizeof(T) * m * n);
     if (rc != ALGP_OK) { hipFree(a.p); hipFree(b.p); hipFree(cc.p); return rc; }
-    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, c->stream, (T*)a.p, m * k, 1u);
-    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, c->stream, (T*)b.p, n * k, 2u);
-    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->stream, (T*)cc.p, m * n, 3u);
+    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, c->cur, (T*)a.p, m * k, 1u);
+    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, c->cur, (T*)b.p, n * k, 2u);
+    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->cur, (T*)cc.p, m * n, 3u);
     const int saved = g_gemm_variant;
     g_gemm_variant = variant;
     hipEvent_t e0, e1;
@@ -416,11 +468,11 @@ int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lo
     for (int w = 0; w < 2 && rc == ALGP_OK; ++w)
         rc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, m, n, k, (T)-1, (const T*)a.p, k, (const T*)b.p, k, beta,
                                (const T*)cc.p, n, (T*)cc.p, n, lower_only);
-    hipEventRecord(e0, c->stream);
+    hipEventRecord(e0, c->cur);
     for (int r = 0; r < reps && rc == ALGP_OK; ++r)
         rc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, m, n, k, (T)-1, (const T*)a.p, k, (const T*)b.p, k, beta,
                                (const T*)cc.p, n, (T*)cc.p, n, lower_only);
-    hipEventRecord(e1, c->stream);
+    hipEventRecord(e1, c->cur);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);

@@ -146,9 +146,9 @@ static int kmat_dispatch(algp_ctx* c, const KmatArgs<T>& a, int DP) {
         const int64_t ny = (gy - y0 < ymax) ? gy - y0 : ymax;
         b.row_base = y0 * 32;
         dim3 grid((unsigned)gx, (unsigned)ny);
-        if (DP == 2) hipLaunchKernelGGL((kmat_kernel<T, 2>), grid, dim3(256), 0, c->stream, b);
-        else if (DP == 4) hipLaunchKernelGGL((kmat_kernel<T, 4>), grid, dim3(256), 0, c->stream, b);
-        else hipLaunchKernelGGL((kmat_kernel<T, 8>), grid, dim3(256), 0, c->stream, b);
+        if (DP == 2) hipLaunchKernelGGL((kmat_kernel<T, 2>), grid, dim3(256), 0, c->cur, b);
+        else if (DP == 4) hipLaunchKernelGGL((kmat_kernel<T, 4>), grid, dim3(256), 0, c->cur, b);
+        else hipLaunchKernelGGL((kmat_kernel<T, 8>), grid, dim3(256), 0, c->cur, b);
     }
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -229,7 +229,7 @@ int scale_coords_launch(algp_ctx* c, const T* x, int64_t n, T* xs) {
     InvLs il;
     for (int d = 0; d < MAXD; ++d) il.v[d] = c->hyp.inv_ls[d];
     const int64_t tot = n * c->hyp.DP;
-    hipLaunchKernelGGL(scale_coords_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, x, n,
+    hipLaunchKernelGGL(scale_coords_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->cur, x, n,
                        c->hyp.D, c->hyp.DP, il, xs);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;

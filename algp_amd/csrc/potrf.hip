@@ -286,7 +286,7 @@ template <typename T>
 int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet_acc, int* info,
                       int64_t block_row0) {
     ProfScope ps(c, ALGP_PROF_POTRF_DIAG, 128.0 * 128.0 * 128.0, sizeof(T) * 3.0 * 128.0 * 128.0);
-    hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(1), dim3(256), 0, c->stream, A, lda, inv_out, logdet_acc,
+    hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(1), dim3(256), 0, c->cur, A, lda, inv_out, logdet_acc,
                        info, block_row0);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -296,7 +296,7 @@ template int potrf_diag_launch<float>(algp_ctx*, float*, int64_t, float*, double
 
 template <typename T>
 int trinv_diag_launch(algp_ctx* c, const T* A, int64_t lda, T* inv_out) {
-    hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(1), dim3(256), 0, c->stream, const_cast<T*>(A), lda, inv_out,
+    hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(1), dim3(256), 0, c->cur, const_cast<T*>(A), lda, inv_out,
                        (double*)nullptr, (int*)nullptr, (int64_t)0);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -314,32 +314,47 @@ template int trinv_diag_launch<float>(algp_ctx*, const float*, int64_t, float*);
 // ---------------------------------------------------------------------------------------------
 constexpr int WB = 512;
 
+// factor block column [j0, j0+w) over all rows >= j0, 128 columns at a time (launches go to c->cur)
+template <typename T>
+static int chol_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info,
+                      int64_t j0, int64_t w) {
+    for (int64_t k0 = j0; k0 < j0 + w; k0 += NB) {
+        T* Akk = A + k0 * ld + k0;
+        T* inv = invD + (k0 / NB) * NB * NB;
+        ALGP_TRY(potrf_diag_launch<T>(c, Akk, ld, inv, logdet_acc, info, k0));
+        const int64_t mrem = npad - (k0 + NB);
+        if (mrem <= 0) continue;
+        T* P = A + (k0 + NB) * ld + k0;                          // rows below the diagonal block
+        ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, NB, NB, (T)1, P, ld, inv, NB, (T)0, nullptr, 0, P,
+                                   ld, 0));
+        const int64_t wrem = j0 + w - (k0 + NB);                 // columns of this block still to do
+        if (wrem > 0) {
+            // A[k0+NB:, k0+NB : j0+w] -= P * P[0:wrem]^T   (K = 128, only inside the block column)
+            T* Cw = A + (k0 + NB) * ld + (k0 + NB);
+            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, wrem, NB, (T)-1, P, ld, P, ld, (T)1, Cw, ld, Cw,
+                                       ld, 0));
+        }
+    }
+    return ALGP_OK;
+}
+
+// Right-looking blocked Cholesky, two-level (512 / 128).
+//
+// Look-ahead (factor block column J+1 on a second stream while the main stream applies block J to
+// the rest) was built and measured in round 1 and is NOT used: the fp64 diagonal kernel needs 134 KB
+// of LDS, i.e. an empty CU, and the trailing-update GEMM keeps two 64 KB workgroups on every CU, so
+// the panel never starts before the GEMM drains (19.8 ms vs 17.6 ms serial at N = 10 000; reserving
+// CUs with a CU-masked stream: 22.1 ms).  It becomes useful once the diagonal kernel fits beside a
+// GEMM workgroup (<= 96 KB: lower-triangular 16 x 16 block storage).
 template <typename T>
 int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
     for (int64_t j0 = 0; j0 < npad; j0 += WB) {
-        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;       // block width (multiple of 128)
-        // ---- factor the block column [j0, j0+w) over all rows >= j0, 128 columns at a time ----
-        for (int64_t k0 = j0; k0 < j0 + w; k0 += NB) {
-            T* Akk = A + k0 * ld + k0;
-            T* inv = invD + (k0 / NB) * NB * NB;
-            ALGP_TRY(potrf_diag_launch<T>(c, Akk, ld, inv, logdet_acc, info, k0));
-            const int64_t mrem = npad - (k0 + NB);
-            if (mrem <= 0) continue;
-            T* P = A + (k0 + NB) * ld + k0;                          // rows below the diagonal block
-            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, NB, NB, (T)1, P, ld, inv, NB, (T)0, nullptr, 0,
-                                       P, ld, 0));
-            const int64_t wrem = j0 + w - (k0 + NB);                 // columns of this block still to do
-            if (wrem > 0) {
-                // A[k0+NB:, k0+NB : j0+w] -= P * P[0:wrem]^T   (K = 128, only inside the block column)
-                T* Cw = A + (k0 + NB) * ld + (k0 + NB);
-                ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, wrem, NB, (T)-1, P, ld, P, ld, (T)1, Cw, ld,
-                                           Cw, ld, 0));
-            }
-        }
-        // ---- trailing update with the whole block: A22 -= P_blk P_blk^T, K = w, lower tiles ----
+        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
+        ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, j0, w));
         const int64_t mrem = npad - (j0 + w);
         if (mrem > 0) {
-            T* Pb = A + (j0 + w) * ld + j0;
+            // trailing update with the whole block: A22 -= P_blk P_blk^T, K = w, lower tiles
+            const T* Pb = A + (j0 + w) * ld + j0;
             T* A22 = A + (j0 + w) * ld + (j0 + w);
             ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, mrem, w, (T)-1, Pb, ld, Pb, ld, (T)1, A22, ld,
                                        A22, ld, 1));
@@ -437,12 +452,12 @@ int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* in
     const int64_t nblk = npad / NB;
     ProfScope ps(c, ALGP_PROF_TRSV, (double)npad * npad, sizeof(T) * 0.5 * (double)npad * npad);
     for (int64_t kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL((diag_matvec_kernel<T, false>), dim3(1), dim3(128), 0, c->stream, invD + kb * NB * NB,
+        hipLaunchKernelGGL((diag_matvec_kernel<T, false>), dim3(1), dim3(128), 0, c->cur, invD + kb * NB * NB,
                            b + kb * NB);
         const int64_t mrem = npad - (kb + 1) * NB;
         if (mrem > 0) {
             const int grid = (int)((mrem + 3) / 4 < 1024 ? (mrem + 3) / 4 : 1024);
-            hipLaunchKernelGGL(panel_gemv_kernel<T>, dim3(grid), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(panel_gemv_kernel<T>, dim3(grid), dim3(256), 0, c->cur,
                                L + (kb + 1) * NB * ldl + kb * NB, ldl, mrem, b + kb * NB, b + (kb + 1) * NB);
         }
     }
@@ -454,11 +469,11 @@ int trsv_backward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* i
     const int64_t nblk = npad / NB;
     ProfScope ps(c, ALGP_PROF_TRSV, (double)npad * npad, sizeof(T) * 0.5 * (double)npad * npad);
     for (int64_t kb = nblk - 1; kb >= 0; --kb) {
-        hipLaunchKernelGGL((diag_matvec_kernel<T, true>), dim3(1), dim3(128), 0, c->stream, invD + kb * NB * NB,
+        hipLaunchKernelGGL((diag_matvec_kernel<T, true>), dim3(1), dim3(128), 0, c->cur, invD + kb * NB * NB,
                            b + kb * NB);
         const int64_t ncol = kb * NB;
         if (ncol > 0) {
-            hipLaunchKernelGGL(panel_gemv_t_kernel<T>, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(panel_gemv_t_kernel<T>, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, c->cur,
                                L + kb * NB * ldl, ldl, ncol, b + kb * NB, b);
         }
     }

@@ -59,9 +59,9 @@ int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int6
     if (g > 8192) g = 8192;
     ProfScope ps(c, ALGP_PROF_ROWS, 2.0 * rows * ncols * ((w ? 1 : 0) + (ss ? 1 : 0)), sizeof(T) * (double)rows * ncols);
     dim3 grid((unsigned)g), blk(256);
-    if (w && ss) hipLaunchKernelGGL((rows_reduce_kernel<T, true, true>), grid, blk, 0, c->stream, Vt, rows, ldv, ncols, w, ss, dot);
-    else if (w) hipLaunchKernelGGL((rows_reduce_kernel<T, true, false>), grid, blk, 0, c->stream, Vt, rows, ldv, ncols, w, ss, dot);
-    else if (ss) hipLaunchKernelGGL((rows_reduce_kernel<T, false, true>), grid, blk, 0, c->stream, Vt, rows, ldv, ncols, w, ss, dot);
+    if (w && ss) hipLaunchKernelGGL((rows_reduce_kernel<T, true, true>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot);
+    else if (w) hipLaunchKernelGGL((rows_reduce_kernel<T, true, false>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot);
+    else if (ss) hipLaunchKernelGGL((rows_reduce_kernel<T, false, true>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -90,7 +90,7 @@ int cand_finalize_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t
                          T prior_const, const T* extra, const T* ss, const T* dot, T ybar, T* dstat, T* mu,
                          unsigned char* alive) {
     if (M <= 0) return ALGP_OK;
-    hipLaunchKernelGGL(cand_finalize_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, M, ckind,
+    hipLaunchKernelGGL(cand_finalize_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->cur, M, ckind,
                        cidx, Cp, n_pool, prior_const, extra, ss, dot, ybar, dstat, mu, alive);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -125,7 +125,7 @@ int score_launch(algp_ctx* c, int64_t M, const int* ckind, const unsigned char* 
                  double delta, const double* extra, double* out) {
     if (M <= 0) return ALGP_OK;
     ProfScope ps(c, ALGP_PROF_SCORE, 4.0 * M, (sizeof(T) + 13.0) * M);
-    hipLaunchKernelGGL(score_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, M, ckind, alive,
+    hipLaunchKernelGGL(score_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->cur, M, ckind, alive,
                        dstat, ss, delta, extra, out);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const double* s, int64_t M
 
 int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx) {
     ProfScope ps(c, ALGP_PROF_SCORE, (double)M, 8.0 * M);
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, s, M, out_val, out_idx);
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->cur, s, M, out_val, out_idx);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -214,7 +214,7 @@ int pick_update_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* 
     ProfScope ps(c, ALGP_PROF_ROWS, 8.0 * M, 4.0 * sizeof(T) * M);
     dim3 grid((unsigned)((M + 255) / 256)), blk(256);
 #define ALGP_PU(DPV)                                                                                            \
-    hipLaunchKernelGGL((pick_update_kernel<T, DPV>), grid, blk, 0, c->stream, M, ckind, cidx, Xs, Cp, n_pool, \
+    hipLaunchKernelGGL((pick_update_kernel<T, DPV>), grid, blk, 0, c->cur, M, ckind, cidx, Xs, Cp, n_pool, \
                        pick_pool, pick_in_train, kernel, os, noise, tvec, scale, dstat, Vt, ldv, col)
     if (DP == 2) ALGP_PU(2);
     else if (DP == 4) ALGP_PU(4);
@@ -276,9 +276,9 @@ int kgemv_launch(algp_ctx* c, int64_t M, const int64_t* qidx, const T* Xs, int D
     if (g > 8192) g = 8192;
     ProfScope ps(c, ALGP_PROF_KMAT, (double)M * N * (3.0 * DP + 4.0), sizeof(T) * (double)(M + N) * (DP + 1));
     dim3 grid((unsigned)g), blk(256);
-    if (DP == 2) hipLaunchKernelGGL((kgemv_kernel<T, 2>), grid, blk, 0, c->stream, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
-    else if (DP == 4) hipLaunchKernelGGL((kgemv_kernel<T, 4>), grid, blk, 0, c->stream, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
-    else hipLaunchKernelGGL((kgemv_kernel<T, 8>), grid, blk, 0, c->stream, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
+    if (DP == 2) hipLaunchKernelGGL((kgemv_kernel<T, 2>), grid, blk, 0, c->cur, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
+    else if (DP == 4) hipLaunchKernelGGL((kgemv_kernel<T, 4>), grid, blk, 0, c->cur, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
+    else hipLaunchKernelGGL((kgemv_kernel<T, 8>), grid, blk, 0, c->cur, M, qidx, Xs, N, aidx, alpha, kernel, os, ybar, mu);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -301,7 +301,7 @@ __global__ void pad_identity_kernel(T* A, int64_t n, int64_t npad, int64_t ld) {
 template <typename T>
 int pad_identity_launch(algp_ctx* c, T* A, int64_t n, int64_t npad, int64_t ld) {
     const int64_t tot = npad * npad;
-    hipLaunchKernelGGL(pad_identity_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, A, n, npad, ld);
+    hipLaunchKernelGGL(pad_identity_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->cur, A, n, npad, ld);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -318,7 +318,7 @@ __global__ void set_identity_kernel(T* A, int64_t npad, int64_t ld) {
 template <typename T>
 int set_identity_launch(algp_ctx* c, T* A, int64_t npad, int64_t ld) {
     const int64_t tot = npad * npad;
-    hipLaunchKernelGGL(set_identity_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, A, npad, ld);
+    hipLaunchKernelGGL(set_identity_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->cur, A, npad, ld);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -333,7 +333,7 @@ __global__ void add_doubles_kernel(double* dst, const T* src, int64_t n) {
 template <typename T>
 int to_double_launch(algp_ctx* c, double* dst, const T* src, int64_t n) {
     if (n <= 0) return ALGP_OK;
-    hipLaunchKernelGGL(add_doubles_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dst, src, n);
+    hipLaunchKernelGGL(add_doubles_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->cur, dst, src, n);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

@@ -56,7 +56,8 @@ enum {
     ALGP_PROF_ROWS = 5,        /* row reductions over V^T (variance, mean, updates) */
     ALGP_PROF_SCORE = 6,       /* score + argmax                                    */
     ALGP_PROF_GEMM_OTHER = 7,
-    ALGP_PROF_COUNT = 8
+    ALGP_PROF_CHOLESKY = 8,    /* wall time of whole train-set factorisations (two overlapped streams) */
+    ALGP_PROF_COUNT = 9
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

@@ -13,9 +13,9 @@ variants = [int(v) for v in sys.argv[2:]] or [0, 1]
 c = _hip.Context(dt)
 shapes = [  # (m, n, k, lower_only, beta_one, label)
     (100096, 128, 128, 0, 0, 'trsm diag   K=128'),
-    (100096, 128, 512, 0, 1, 'trsm update K=512'),
-    (100096, 128, 2048, 0, 1, 'trsm update K=2048'),
-    (100096, 128, 8192, 0, 1, 'trsm update K=8192'),
+    (100096, 128, 384, 0, 1, 'trsm inblk  K=384'),
+    (100096, 512, 2048, 0, 1, 'trsm outer n=512 K=2048'),
+    (100096, 512, 8192, 0, 1, 'trsm outer n=512 K=8192'),
     (9984, 128, 128, 0, 0, 'chol panel  m=9984'),
     (9984, 9984, 128, 1, 1, 'chol syrk   m=9984 K=128'),
     (4992, 4992, 128, 1, 1, 'chol syrk   m=4992 K=128'),
