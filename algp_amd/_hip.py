@@ -37,6 +37,7 @@ SIGNATURES = {
     'algp_set_pool_cov': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64]),
     'algp_set_train': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p, C.c_void_p]),
     'algp_factorize': (C.c_int, [_c_ctx]),
+    'algp_factorize_update': (C.c_int, [_c_ctx, _i64p]),
     'algp_get_logdet': (C.c_int, [_c_ctx, _dblp]),
     'algp_get_entropy': (C.c_int, [_c_ctx, _dblp]),
     'algp_get_alpha': (C.c_int, [_c_ctx, C.c_void_p]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     'algp_get_mll_grad': (C.c_int, [_c_ctx, _dblp]),
     'algp_set_candidates': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_int, C.c_void_p]),
     'algp_solve_candidates': (C.c_int, [_c_ctx]),
+    'algp_solve_candidates_update': (C.c_int, [_c_ctx, C.c_void_p, _i64p]),
     'algp_get_posterior': (C.c_int, [_c_ctx, C.c_void_p, C.c_void_p]),
     'algp_get_posterior_cov': (C.c_int, [_c_ctx, C.c_void_p, _dblp]),
     'algp_posterior_mean': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p]),
@@ -199,8 +201,14 @@ class Context(object):
         self.N = len(idx)
         self._check(self.lib.algp_set_train(self.h, _i64(idx), len(idx), _ptr(y), _ptr(v)))
 
-    def factorize(self):
-        self._check(self.lib.algp_factorize(self.h))
+    def factorize(self, incremental=False):
+        """incremental=True reuses the resident factor's unchanged leading rows (returns how many)."""
+        if not incremental:
+            self._check(self.lib.algp_factorize(self.h))
+            return 0
+        kept = C.c_int64()
+        self._check(self.lib.algp_factorize_update(self.h, C.byref(kept)))
+        return kept.value
 
     def _get_double(self, fn):
         v = C.c_double()
@@ -239,8 +247,17 @@ class Context(object):
         self.M = len(idx)
         self._check(self.lib.algp_set_candidates(self.h, _i64(idx), len(idx), int(bool(prior_includes_noise)), _ptr(e)))
 
-    def solve_candidates(self):
-        self._check(self.lib.algp_solve_candidates(self.h))
+    def solve_candidates(self, incremental=False, alive=None):
+        """incremental=True keeps the V^T columns that are still valid (returns how many columns)."""
+        if not incremental and alive is None:
+            self._check(self.lib.algp_solve_candidates(self.h))
+            return 0
+        a = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint8)
+        if a is not None and a.shape != (self.M,):
+            raise ValueError('alive must have one entry per candidate')
+        kept = C.c_int64()
+        self._check(self.lib.algp_solve_candidates_update(self.h, _ptr(a), C.byref(kept)))
+        return kept.value
 
     def posterior(self, want_var=True):
         mu = np.empty(self.M, dtype=self.dtype)

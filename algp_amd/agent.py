@@ -48,6 +48,14 @@ class Agent(object):
         self._cov_matrix = None
         self._cov_matrix_user = False
         self._pool_key = None
+        # f1: keep the factor across planning steps.  The train set is handed to the
+        # device in INSERTION order (a site is appended the first time it is sampled), the candidate
+        # list is the whole pool with an alive mask, and predict() has its own context over a fixed
+        # [env.X; env.test_X] pool -- so each step re-factorises / re-solves only what changed.
+        self.incremental = getattr(args, 'incremental', True)
+        self._order = []
+        self._pctx = None
+        self._pctx_key = None
         self.reset()
         if parent_agent is None:
             self._pre_train(num_samples=int(args.fraction_pretrain * self.env.num_samples))
@@ -79,6 +87,7 @@ class Agent(object):
         self.static_locations = np.empty((0, 2))
         self.static_data = [[] for _ in range(self.env.num_samples)]
         self.mobile_data = [[] for _ in range(self.env.num_samples)]
+        self._order = []
 
     def _pre_train(self, num_samples):
         print('====================================================')
@@ -97,6 +106,8 @@ class Agent(object):
                 continue
             y = self.env.collect_samples(idx, sd)
             ys[k] = y
+            if not self.static_data[idx] and not self.mobile_data[idx]:
+                self._order.append(int(idx))                 # first reading at this site
             (self.static_data if sd == self.static_std else self.mobile_data)[idx].append(y)
         self.collected['ind'] += list(indices)
         self.collected['std'] += list(stds)
@@ -179,22 +190,77 @@ class Agent(object):
         self._post_update()
 
     def predict(self, x=None, return_var=False, return_cov=False, return_mi=False):
-        x = self.env.test_X if x is None else x
         ind, y, var = self.get_sampled_dataset()
+        if x is None and getattr(self, 'incremental', False) and not self._cov_matrix_user:
+            return self._predict_incremental(ind, y, var, return_var, return_cov, return_mi)
+        x = self.env.test_X if x is None else x
         self._pool_key = None                                       # predictive_distribution reloads the pool
         return predictive_distribution(self.gp, self.env.X[ind], y, x, var, return_var=return_var,
                                        return_cov=return_cov, return_mi=return_mi)
+
+    def _predict_incremental(self, ind, y, var, return_var, return_cov, return_mi):
+        """utils.predictive_distribution on the held-out set, with the factor kept across calls."""
+        n, m = self.env.num_samples, len(self.env.test_X)
+        hkey = self.gp.hypers()
+        key = (tuple(hkey[0]), hkey[1], hkey[2], hkey[3], id(self.env.X), id(self.env.test_X))
+        if self._pctx is None:
+            self._pctx = _hip.Context(self.gp.dtype, self.gp.device)
+        c = self._pctx
+        if key != self._pctx_key:
+            c.set_hypers(hkey[0], hkey[1], hkey[2], hkey[3])
+            c.set_pool(np.vstack([np.asarray(self.env.X, np.float64).reshape(n, -1),
+                                  np.asarray(self.env.test_X, np.float64).reshape(m, -1)]))
+            self._pctx_key = key
+        pos = {int(i): k for k, i in enumerate(ind)}
+        sampled = np.zeros(n, bool)
+        sampled[ind] = True
+        A = self._train_order(sampled)
+        sel = np.array([pos[int(i)] for i in A], dtype=np.int64)
+        c.set_train(A, y[sel] if len(sel) else y, var[sel] if len(sel) else var)
+        c.factorize(incremental=True)
+        test_idx = np.arange(n, n + m)
+        if not (return_var or return_cov or return_mi):
+            return c.posterior_mean(test_idx)
+        c.set_candidates(test_idx, prior_includes_noise=False)
+        c.solve_candidates(incremental=True)
+        mu, pv = c.posterior()
+        res = (mu, pv) if return_var else None
+        if return_cov or return_mi:
+            cov, mi = c.posterior_cov(want_cov=return_cov, want_mi=return_mi)
+            if return_cov:
+                res = (mu, cov)
+            if return_mi:
+                res = (mu, mi)
+            if return_cov and return_mi:
+                res = (mu, cov, mi)
+        return res
+
+    def _train_order(self, sampled):
+        """Sampled sites in insertion order (falls back to index order for sites whose first
+        reading was not seen by _add_samples, e.g. data copied from a parent agent)."""
+        seen = set()
+        order = [i for i in getattr(self, '_order', []) if sampled[i] and not (i in seen or seen.add(i))]
+        if len(order) != int(sampled.sum()):
+            order += [int(i) for i in np.where(sampled)[0] if i not in seen]
+        return np.array(order, dtype=np.int64)
 
     def greedy(self, num_samples):
         """k most informative static sampling sites, greedily (agent.py:295-356)."""
         c = self._load_pool()
         static, mobile = self._masks()
         sampled = static | mobile
-        A = np.where(sampled)[0]
-        c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
-        c.factorize()
-        c.set_candidates(np.where(~static)[0], prior_includes_noise=True)
-        c.solve_candidates()
+        if getattr(self, 'incremental', False):
+            A = self._train_order(sampled)
+            c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
+            c.factorize(incremental=True)
+            c.set_candidates(np.arange(self.env.num_samples), prior_includes_noise=True)
+            c.solve_candidates(incremental=True, alive=~static)
+        else:
+            A = np.where(sampled)[0]
+            c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
+            c.factorize()
+            c.set_candidates(np.where(~static)[0], prior_includes_noise=True)
+            c.solve_candidates()
         picks = c.greedy(_CRIT[self.criterion], self.static_std, self.mobile_std, int(num_samples))
         return [int(p) for p in picks]
 

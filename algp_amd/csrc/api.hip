@@ -235,23 +235,28 @@ struct Impl {
         ALGP_HIP(hipMemcpyAsync(c->y0.p, y0.data(), sizeof(T) * Npad, hipMemcpyHostToDevice, c->stream));
         ALGP_HIP(hipMemcpyAsync(c->varA.p, vv.data(), sizeof(T) * Npad, hipMemcpyHostToDevice, c->stream));
         ALGP_TRY(sync(c));   // host vectors go out of scope
-        c->factored = false;
+        c->train_var_host.assign(N, 0.0);
+        if (var)
+            for (int64_t i = 0; i < N; ++i) c->train_var_host[i] = (double)((const T*)var)[i];
+        c->train_dirty = true;       // the resident factor (if any) still describes fact_idx / fact_var
         c->solved = false;
         return ALGP_OK;
     }
 
     // factor an npad x npad matrix already resident in A; returns logdet; NOT_PD -> error with pivot
     static int factor_resident(algp_ctx* c, T* A, int64_t n, int64_t npad, T* invD, int slot_logdet, int slot_info,
-                               double* logdet) {
+                               double* logdet, int64_t ld = 0, int64_t pivot_offset = 0) {
+        if (ld == 0) ld = npad;
         double* sc = (double*)c->scal.p;
         ALGP_HIP(hipMemsetAsync(sc + slot_logdet, 0, 2 * sizeof(double), c->stream));
-        ALGP_TRY(cholesky_blocked<T>(c, A, npad, npad, invD, sc + slot_logdet, (int*)(sc + slot_info)));
+        ALGP_TRY(cholesky_blocked<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info)));
         double host[2];
         ALGP_HIP(hipMemcpyAsync(host, sc + slot_logdet, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         ALGP_TRY(sync(c));
         int info;
         memcpy(&info, &host[1], sizeof(int));
         if (info != 0) {
+            info += (int)pivot_offset;
             c->pivot = info;
             return fail(c, ALGP_ERR_NOT_PD,
                         "matrix is not positive definite: non-positive pivot at index " + std::to_string(info) +
@@ -261,27 +266,96 @@ struct Impl {
         return ALGP_OK;
     }
 
-    static int factorize(algp_ctx* c) {
+    // make room for an Npad x Npad factor with leading dimension Lld >= Npad, keeping the first
+    // `keep_rows` rows (and their inverse diagonal blocks) when the buffers have to grow
+    static int reserve_factor(algp_ctx* c, int64_t npad_need, int64_t keep_rows) {
+        if (c->Lld >= npad_need && c->L.p && c->invD.p) return ALGP_OK;
+        const int64_t newld = round_up(std::max<int64_t>(npad_need, c->Lld + c->Lld / 4), NB);
+        DevBuf nl, ni;
+        int rc = ensure(c, nl, sizeof(T) * newld * newld);
+        if (rc == ALGP_OK) rc = ensure(c, ni, sizeof(T) * newld * NB);
+        if (rc != ALGP_OK) { release(c, nl); release(c, ni); return rc; }
+        if (keep_rows > 0 && c->L.p) {
+            hipError_t e = hipMemcpy2DAsync(nl.p, sizeof(T) * newld, c->L.p, sizeof(T) * c->Lld, sizeof(T) * keep_rows,
+                                            keep_rows, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(ni.p, c->invD.p, sizeof(T) * keep_rows * NB, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) { release(c, nl); release(c, ni); return fail(c, ALGP_ERR_HIP, hipGetErrorString(e)); }
+            hipStreamSynchronize(c->stream);
+        }
+        release(c, c->L);
+        release(c, c->invD);
+        c->L = nl;
+        c->invD = ni;
+        c->Lld = newld;
+        return ALGP_OK;
+    }
+
+    // S = C_AA + D -> L.  With `incremental`, the leading 128-row blocks of the resident factor are
+    // kept as long as the train set (indices, noise, in order) and the hyper-parameters agree with
+    // what they were computed for; only the rows from the first changed block on are rebuilt:
+    //   rows R of S regenerated, X = S[R, 0:Nb] L[0:Nb,0:Nb]^-T, S_RR -= X X^T, chol(S_RR).
+    // Appending k sites to N therefore costs O((128 + k) N^2) instead of O(N^3 / 3).
+    static int factorize(algp_ctx* c, int incremental) {
         const int64_t N = c->N, Npad = c->Npad;
+        int64_t keep = 0;                                        // rows of the resident factor to keep
+        if (incremental && c->factored && c->fact_hyp_stamp == c->hyp_stamp && c->Lld > 0) {
+            const int64_t lim = std::min<int64_t>(N, c->Nfact);
+            int64_t p0 = 0;
+            while (p0 < lim && c->fact_idx[p0] == c->train_idx[p0] && c->fact_var[p0] == c->train_var_host[p0]) ++p0;
+            keep = p0 / NB * NB;
+        }
         c->factored = false;
         c->solved = false;
-        ALGP_TRY(ensure(c, c->L, sizeof(T) * Npad * Npad));
-        ALGP_TRY(ensure(c, c->invD, sizeof(T) * Npad * NB));
+        ALGP_TRY(reserve_factor(c, Npad, keep));
+        const int64_t ld = c->Lld;
         ALGP_TRY(ensure(c, c->z, sizeof(T) * Npad));
         ALGP_TRY(ensure(c, c->alpha, sizeof(T) * Npad));
         KmatSrc s = make_src(c);
-        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p, N, Npad, (const int64_t*)c->Aidx.p, N, Npad,
-                                (const T*)c->varA.p, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->L), Npad));
-        double ld = 0;
-        prof_span_begin(c, ALGP_PROF_CHOLESKY, (double)N * N * N / 3.0, sizeof(T) * (double)N * N);
-        int frc = factor_resident(c, p(c->L), N, Npad, p(c->invD), SC_LOGDET, SC_INFO, &ld);
+        double ld_total = 0;
+        prof_span_begin(c, ALGP_PROF_CHOLESKY, keep == 0 ? (double)N * N * N / 3.0 : (double)(N - keep) * N * N,
+                        sizeof(T) * (double)N * N);
+        int frc = ALGP_OK;
+        if (keep == 0) {
+            frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p, N, Npad, (const int64_t*)c->Aidx.p, N, Npad,
+                                 (const T*)c->varA.p, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->L), ld);
+            if (frc == ALGP_OK)
+                frc = factor_resident(c, p(c->L), N, Npad, p(c->invD), SC_LOGDET, SC_INFO, &ld_total, ld);
+        } else {
+            const int64_t Nb = keep, R = Npad - Nb;
+            T* rows = p(c->L) + Nb * ld;
+            // regenerate rows [Nb, Npad) of S (all columns), identity on the padded diagonal
+            frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p + Nb, N - Nb, R, (const int64_t*)c->Aidx.p, N, Npad,
+                                 (const T*)c->varA.p + Nb, c->pool_is_cov ? 0 : 1, nullptr, 1, rows, ld, Nb);
+            // X = S[R, 0:Nb] L11^-T  (in place, against the kept blocks only)
+            if (frc == ALGP_OK)
+                frc = trsm_blocked<T>(c, ALGP_PROF_GEMM_CHOL, rows, R, ld, p(c->L), Nb, ld, p(c->invD));
+            // S_RR -= X X^T
+            if (frc == ALGP_OK)
+                frc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, R, R, Nb, (T)-1, rows, ld, rows, ld, (T)1, rows + Nb, ld,
+                                        rows + Nb, ld, 1);
+            double ld_tail = 0;
+            if (frc == ALGP_OK)
+                frc = factor_resident(c, rows + Nb, N - Nb, R, p(c->invD) + Nb * NB, SC_LOGDET, SC_INFO, &ld_tail, ld, Nb);
+            if (frc == ALGP_OK) {
+                // log det over the whole diagonal (the kept blocks' share is not stored separately)
+                double* sc = (double*)c->scal.p;
+                hipMemsetAsync(sc + SC_AUXLOGDET, 0, sizeof(double), c->stream);
+                frc = logdiag_launch<T>(c, p(c->L), ld, N, sc + SC_AUXLOGDET);
+                if (frc == ALGP_OK) {
+                    hipMemcpyAsync(&ld_total, sc + SC_AUXLOGDET, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+                    frc = sync(c);
+                    ld_total *= 2.0;
+                }
+            }
+        }
         prof_span_end(c);
         ALGP_TRY(frc);
-        c->logdet = ld;
+        c->logdet = ld_total;
         ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
-        ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, Npad, p(c->invD), p(c->z)));
+        ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z)));
         ALGP_HIP(hipMemcpyAsync(c->alpha.p, c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
-        ALGP_TRY(trsv_backward<T>(c, p(c->L), Npad, Npad, p(c->invD), p(c->alpha)));
+        ALGP_TRY(trsv_backward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->alpha)));
         std::vector<T> zh(Npad);
         ALGP_HIP(hipMemcpyAsync(zh.data(), c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToHost, c->stream));
         ALGP_TRY(sync(c));
@@ -289,6 +363,12 @@ struct Impl {
         for (int64_t i = 0; i < N; ++i) q += (double)zh[i] * (double)zh[i];
         c->yalpha = q;    // y0' S^-1 y0 = |L^-1 y0|^2
         c->factored = true;
+        c->train_dirty = false;
+        c->Nfact = N;
+        c->fact_idx = c->train_idx;
+        c->fact_var = c->train_var_host;
+        c->fact_hyp_stamp = c->hyp_stamp;
+        c->kept_rows_last = keep;
         return ALGP_OK;
     }
 
@@ -315,20 +395,47 @@ struct Impl {
         return ALGP_OK;
     }
 
-    static int solve_candidates(algp_ctx* c) {
-        if (!c->factored) return fail(c, ALGP_ERR_STATE, "solve_candidates: call algp_factorize first");
+    // V^T = B^T L^-T for the candidate list, then pv / s / mu.  With `incremental`, the columns that
+    // were solved against rows of the factor that are unchanged (same leading train rows, same
+    // hyper-parameters, same candidate list) are kept and only the trailing column blocks are solved.
+    // `alive` (M bytes, may be null) disables candidates (sites that became static-sampled).
+    static int solve_candidates(algp_ctx* c, int incremental, const unsigned char* alive_host) {
+        if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "solve_candidates: call algp_factorize first");
         const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad;
         const int64_t ldv = Npad + MAX_APPEND;
-        c->ldv = ldv;
+        int64_t keep = 0;
+        if (incremental && c->Vt.p && c->vt_hyp_stamp == c->hyp_stamp && c->vt_prior_noise == c->prior_noise &&
+            !c->vt_has_extra && !c->cextra.p && c->vt_cand_idx == c->cand_idx) {
+            const int64_t lim = std::min<int64_t>((int64_t)c->vt_fact_idx.size(), N);
+            int64_t p0 = 0;
+            while (p0 < lim && c->vt_fact_idx[p0] == c->fact_idx[p0] && c->vt_fact_var[p0] == c->fact_var[p0]) ++p0;
+            keep = p0 / NB * NB;
+        }
         c->solved = false;
-        ALGP_TRY(ensure(c, c->Vt, sizeof(T) * Mpad * ldv));
+        if (!c->Vt.p || c->ldv_cap < ldv || (keep == 0 && c->ldv_cap != ldv) || c->Vt.cap < sizeof(T) * Mpad * c->ldv_cap) {
+            // (re)allocate; keep the valid columns when growing
+            const int64_t newcap = keep > 0 ? round_up(ldv + ldv / 8, NB) : ldv;
+            DevBuf nv;
+            ALGP_TRY(ensure(c, nv, sizeof(T) * Mpad * newcap));
+            if (keep > 0) {
+                hipError_t e = hipMemcpy2DAsync(nv.p, sizeof(T) * newcap, c->Vt.p, sizeof(T) * c->ldv_cap, sizeof(T) * keep,
+                                                Mpad, hipMemcpyDeviceToDevice, c->stream);
+                if (e != hipSuccess) { release(c, nv); return fail(c, ALGP_ERR_HIP, hipGetErrorString(e)); }
+                hipStreamSynchronize(c->stream);
+            }
+            release(c, c->Vt);
+            c->Vt = nv;
+            c->ldv_cap = newcap;
+        }
+        const int64_t ldc = c->ldv_cap;          // row stride of V^T
+        c->ldv = ldc;
         ALGP_TRY(ensure(c, c->dstat, sizeof(T) * Mpad));
         ALGP_TRY(ensure(c, c->mu, sizeof(T) * Mpad));
         ALGP_TRY(ensure(c, c->tvec, sizeof(T) * 2 * Mpad));
         ALGP_TRY(ensure(c, c->alive, Mpad));
         ALGP_TRY(ensure(c, c->scores, sizeof(double) * Mpad));
-        ALGP_TRY(ensure(c, c->lrow, sizeof(T) * ldv));
-        ALGP_TRY(ensure(c, c->prevrows, sizeof(T) * MAX_APPEND * ldv));
+        ALGP_TRY(ensure(c, c->lrow, sizeof(T) * ldc));
+        ALGP_TRY(ensure(c, c->prevrows, sizeof(T) * MAX_APPEND * ldc));
         {
             // greedy semantics: a candidate that is a train site is the unit vector e_pos (its
             // noise changes); predictive semantics: it is an ordinary point at the same location
@@ -340,22 +447,32 @@ struct Impl {
             ALGP_TRY(sync(c));
         }
         KmatSrc s = make_src(c);
-        // B^T: row j = C[cand_j, A] (ordinary) or e_pos (train-site candidate); zero padding
-        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Aidx.p, N, ldv, nullptr, 0,
-                                c->prior_noise ? (const int*)c->ckind.p : nullptr, 0, p(c->Vt), ldv));
-        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldv, p(c->L), Npad, Npad, p(c->invD)));
+        // B^T: row j = C[cand_j, A] (ordinary) or e_pos (train-site candidate); zero padding.
+        // Only columns >= keep are (re)generated and solved.
+        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Aidx.p + keep, N - keep,
+                                ldv - keep, nullptr, 0, c->prior_noise ? (const int*)c->ckind.p : nullptr, 0,
+                                p(c->Vt) + keep, ldc, 0, keep));
+        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), Npad, c->Lld, p(c->invD), keep));
         T* ss = p(c->tvec);
         T* dot = ss + Mpad;
-        ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), M, ldv, Npad, p(c->z), ss, dot));
+        ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), M, ldc, Npad, p(c->z), ss, dot));
         const T prior = (T)(c->hyp.outputscale + (c->prior_noise ? c->hyp.noise : 0.0));
         ALGP_TRY(cand_finalize_launch<T>(c, M, (const int*)c->ckind.p, (const int64_t*)c->Cidx.p,
                                          c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, prior,
                                          c->cextra.p ? (const T*)c->cextra.p : nullptr, ss, dot, (T)c->ybar, p(c->dstat),
                                          p(c->mu), (unsigned char*)c->alive.p));
+        if (alive_host) ALGP_HIP(hipMemcpyAsync(c->alive.p, alive_host, M, hipMemcpyHostToDevice, c->stream));
         ALGP_TRY(sync(c));
         c->ncols = Npad;
         c->picks.clear();
         c->solved = true;
+        c->vt_fact_idx = c->fact_idx;
+        c->vt_fact_var = c->fact_var;
+        c->vt_cand_idx = c->cand_idx;
+        c->vt_hyp_stamp = c->hyp_stamp;
+        c->vt_prior_noise = c->prior_noise;
+        c->vt_has_extra = c->cextra.p != nullptr;
+        c->kept_cols_last = keep;
         return ALGP_OK;
     }
 
@@ -395,7 +512,7 @@ struct Impl {
     }
 
     static int posterior_mean(algp_ctx* c, const int64_t* idx, int64_t M, void* mu_out) {
-        if (!c->factored) return fail(c, ALGP_ERR_STATE, "posterior_mean: call algp_factorize first");
+        if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "posterior_mean: call algp_factorize first");
         if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "posterior_mean needs a coordinate pool");
         if (M == 0) return ALGP_OK;
         ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * M));
@@ -629,7 +746,7 @@ struct Impl {
         KmatSrc s = make_src(c);
         ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->auxIdx.p, 1, 1, (const int64_t*)c->Aidx.p, N, Npad, nullptr, 0,
                                 unit_dev, 0, l, ldv));
-        ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, Npad, p(c->invD), l));
+        ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, c->Lld, p(c->invD), l));
         // host finishes the (at most MAX_APPEND) appended entries: tiny dot products on downloaded rows
         std::vector<T> lh(ldv);
         ALGP_HIP(hipMemcpyAsync(lh.data(), l, sizeof(T) * ldv, hipMemcpyDeviceToHost, c->stream));
@@ -743,7 +860,7 @@ struct Impl {
     }
 
     static int mll_grad(algp_ctx* c, double* grad_out) {
-        if (!c->factored) return fail(c, ALGP_ERR_STATE, "get_mll_grad: call algp_factorize first");
+        if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_mll_grad: call algp_factorize first");
         if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "get_mll_grad needs a coordinate pool");
         const int64_t N = c->N, Npad = c->Npad;
         const int D = c->hyp.D, DP = c->hyp.DP;
@@ -751,7 +868,7 @@ struct Impl {
         ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Npad * Npad));
         // X = I L^-T = L^-T ;  S^-1 = X X^T (lower tiles)
         ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), Npad, Npad));
-        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), Npad, Npad, p(c->invD)));
+        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), Npad, c->Lld, p(c->invD)));
         ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, Npad, Npad, Npad, (T)1, p(c->auxW), Npad, p(c->auxW), Npad,
                                    (T)0, nullptr, 0, p(c->auxA), Npad, 1));
         double* sc = (double*)c->scal.p + 16;             // slots 16..27: os, trace, ls[0..8)
@@ -768,14 +885,14 @@ struct Impl {
     }
 
     static int get_alpha(algp_ctx* c, void* out) {
-        if (!c->factored) return fail(c, ALGP_ERR_STATE, "get_alpha: call algp_factorize first");
+        if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_alpha: call algp_factorize first");
         ALGP_HIP(hipMemcpyAsync(out, c->alpha.p, sizeof(T) * c->N, hipMemcpyDeviceToHost, c->stream));
         return sync(c);
     }
     static int get_factor(algp_ctx* c, void* out) {
-        if (!c->factored) return fail(c, ALGP_ERR_STATE, "get_factor: call algp_factorize first");
+        if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_factor: call algp_factorize first");
         const int64_t N = c->N;
-        ALGP_HIP(hipMemcpy2DAsync(out, sizeof(T) * N, c->L.p, sizeof(T) * c->Npad, sizeof(T) * N, N, hipMemcpyDeviceToHost, c->stream));
+        ALGP_HIP(hipMemcpy2DAsync(out, sizeof(T) * N, c->L.p, sizeof(T) * c->Lld, sizeof(T) * N, N, hipMemcpyDeviceToHost, c->stream));
         ALGP_TRY(sync(c));
         T* Lh = (T*)out;
         for (int64_t i = 0; i < N; ++i)
@@ -870,6 +987,7 @@ int algp_set_hypers(algp_ctx* c, int kernel, int D, const double* log_ls, double
     c->hyp.outputscale = exp(log_os);
     c->hyp.noise = exp(log_noise);
     c->hyp.set = true;
+    c->hyp_stamp++;
     c->factored = false;
     c->solved = false;
     FINISH(c, DISPATCH(c, rescale_pool(c)));
@@ -888,6 +1006,7 @@ int algp_set_pool(algp_ctx* c, const void* x, int64_t n) {
     NEED_HYPERS(c);
     if (!x || n <= 0) return fail(c, ALGP_ERR_BAD_ARG, "set_pool: bad arguments");
     c->factored = c->solved = false;
+    c->hyp_stamp++;
     c->pos_in_train.clear();
     c->N = 0;
     FINISH(c, DISPATCH(c, set_pool(c, x, n)));
@@ -898,6 +1017,7 @@ int algp_set_pool_cov(algp_ctx* c, const void* cov, int64_t n) {
     NEED_HYPERS(c);
     if (!cov || n <= 0) return fail(c, ALGP_ERR_BAD_ARG, "set_pool_cov: bad arguments");
     c->factored = c->solved = false;
+    c->hyp_stamp++;
     c->pos_in_train.clear();
     c->N = 0;
     FINISH(c, DISPATCH(c, set_pool_cov(c, cov, n)));
@@ -924,24 +1044,36 @@ int algp_factorize(algp_ctx* c) {
     // but it has to be declared through algp_set_train(ctx, NULL, 0, NULL, NULL)
     if (!c->y0.p || (int64_t)c->pos_in_train.size() != c->n_pool)
         return fail(c, ALGP_ERR_STATE, "factorize: call algp_set_train first");
-    FINISH(c, DISPATCH(c, factorize(c)));
+    FINISH(c, DISPATCH(c, factorize(c, 0)));
+}
+
+int algp_factorize_update(algp_ctx* c, int64_t* kept_rows) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (c->n_pool <= 0) return fail(c, ALGP_ERR_STATE, "factorize_update: set a pool first");
+    if (!c->y0.p || (int64_t)c->pos_in_train.size() != c->n_pool)
+        return fail(c, ALGP_ERR_STATE, "factorize_update: call algp_set_train first");
+    int rc = DISPATCH(c, factorize(c, 1));
+    if (kept_rows) *kept_rows = rc == ALGP_OK ? c->kept_rows_last : 0;
+    if (c->prof_on) prof_collect(c);
+    return rc;
 }
 
 int algp_get_logdet(algp_ctx* c, double* logdet) {
     CHECK_CTX(c);
-    if (!c->factored || !logdet) return fail(c, ALGP_ERR_STATE, "get_logdet: call algp_factorize first");
+    if (!c->factored || c->train_dirty || !logdet) return fail(c, ALGP_ERR_STATE, "get_logdet: call algp_factorize first");
     *logdet = c->logdet;
     return ALGP_OK;
 }
 int algp_get_entropy(algp_ctx* c, double* H) {
     CHECK_CTX(c);
-    if (!c->factored || !H) return fail(c, ALGP_ERR_STATE, "get_entropy: call algp_factorize first");
+    if (!c->factored || c->train_dirty || !H) return fail(c, ALGP_ERR_STATE, "get_entropy: call algp_factorize first");
     *H = (double)c->N * ENT_CONST + 0.5 * c->logdet;
     return ALGP_OK;
 }
 int algp_get_mll(algp_ctx* c, double* mll) {
     CHECK_CTX(c);
-    if (!c->factored || !mll) return fail(c, ALGP_ERR_STATE, "get_mll: call algp_factorize first");
+    if (!c->factored || c->train_dirty || !mll) return fail(c, ALGP_ERR_STATE, "get_mll: call algp_factorize first");
     *mll = -0.5 * c->yalpha - 0.5 * c->logdet - 0.5 * (double)c->N * 1.8378770664093453;
     return ALGP_OK;
 }
@@ -961,7 +1093,14 @@ int algp_set_candidates(algp_ctx* c, const int64_t* idx, int64_t M, int prior_no
         if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "set_candidates: index outside the pool");
     FINISH(c, DISPATCH(c, set_candidates(c, idx, M, prior_noise, extra)));
 }
-int algp_solve_candidates(algp_ctx* c) { CHECK_CTX(c); FINISH(c, DISPATCH(c, solve_candidates(c))); }
+int algp_solve_candidates(algp_ctx* c) { CHECK_CTX(c); FINISH(c, DISPATCH(c, solve_candidates(c, 0, nullptr))); }
+int algp_solve_candidates_update(algp_ctx* c, const uint8_t* alive, int64_t* kept_cols) {
+    CHECK_CTX(c);
+    int rc = DISPATCH(c, solve_candidates(c, 1, alive));
+    if (kept_cols) *kept_cols = rc == ALGP_OK ? c->kept_cols_last : 0;
+    if (c->prof_on) prof_collect(c);
+    return rc;
+}
 int algp_get_posterior(algp_ctx* c, void* mu, void* var) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_posterior(c, mu, var))); }
 int algp_get_posterior_cov(algp_ctx* c, void* cov, double* mi) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_posterior_cov(c, cov, mi))); }
 int algp_posterior_mean(algp_ctx* c, const int64_t* idx, int64_t M, void* mu) {

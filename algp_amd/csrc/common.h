@@ -68,6 +68,14 @@ struct algp_ctx {
 
     // train set / factor
     int64_t N = 0, Npad = 0;
+    int64_t Lld = 0;                     // leading dimension (= capacity) of L; >= Npad
+    int64_t Nfact = 0;                   // rows of L that are valid for (fact_idx, fact_var)
+    std::vector<int64_t> fact_idx;       // train set the resident factor was computed for
+    std::vector<double> fact_var;
+    std::vector<double> train_var_host;
+    uint64_t fact_hyp_stamp = 0, hyp_stamp = 1;
+    bool train_dirty = false;
+    int64_t kept_rows_last = 0;
     std::vector<int64_t> train_idx;
     algp::DevBuf Aidx, yA, varA, y0, L, invD, z, alpha, scal;   // scal: device doubles (logdet, info...)
     double ybar = 0, logdet = 0, yalpha = 0;
@@ -83,6 +91,14 @@ struct algp_ctx {
     std::vector<algp::PickRec> picks;
     algp::DevBuf prevrows;   // MAX_APPEND x ldv: the l-rows of committed picks
     bool solved = false;
+    int64_t ldv_cap = 0;                 // allocated leading dimension of V^T
+    // what the resident V^T columns were solved for (incremental candidate solve)
+    std::vector<int64_t> vt_fact_idx, vt_cand_idx;
+    std::vector<double> vt_fact_var;
+    uint64_t vt_hyp_stamp = 0;
+    int vt_prior_noise = -1;
+    bool vt_has_extra = false;
+    int64_t kept_cols_last = 0;
 
     // scratch for auxiliary factorizations (entropy_from_cov, set entropies, MI terms, posterior cov)
     algp::DevBuf auxA, auxInv, auxW, auxIdx, auxVar, auxD, hostStage;
@@ -143,7 +159,8 @@ struct KmatSrc {
 template <typename T>
 int kmat_launch(algp_ctx* c, const KmatSrc& s, const int64_t* ridx, int64_t rows, int64_t rows_pad,
                 const int64_t* cidx, int64_t cols, int64_t cols_pad, const T* diag_add,
-                int add_noise_on_equal, const int* unit, int identity_pad, T* out, int64_t ldo);
+                int add_noise_on_equal, const int* unit, int identity_pad, T* out, int64_t ldo,
+                int64_t ident_shift = 0, int64_t col_shift = 0);
 
 // plain (non-pool) kernel matrix between two scaled coordinate arrays, for algp_kernel_matrix
 template <typename T>
@@ -170,7 +187,7 @@ int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doubl
 // X (mpad x npad, ld ldx) <- X * L^-T, in place
 template <typename T>
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                 int64_t ldl, const T* invD);
+                 int64_t ldl, const T* invD, int64_t col_start = 0);
 // b <- L^-1 b (forward) and b <- L^-T b (backward) for one vector of length npad
 template <typename T>
 int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b);

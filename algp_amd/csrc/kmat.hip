@@ -43,6 +43,8 @@ struct KmatArgs {
     int same_pool;          // row and column indices address the same pool (equality is meaningful)
     const int* unit;        // unit[r] >= 0: row r is the unit vector e_{unit[r]} (null: none)
     int identity_pad;
+    int64_t ident_shift;    // identity padding sits at column r + ident_shift (row windows of a larger matrix)
+    int64_t col_shift;      // global column of local column 0 (unit rows compare global columns)
     int kernel;
     T outputscale;
     T* out;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
                 T val = (T)0;
                 if (c < a.cols) {
                     if (u >= 0) {
-                        val = (c == (int64_t)u) ? (T)1 : (T)0;
+                        val = (c + a.col_shift == (int64_t)u) ? (T)1 : (T)0;
                     } else {
                         if (a.Cp) {
                             val = a.Cp[pr * a.n_pool + pc[v]];
@@ -119,14 +121,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
                             if (a.diag_add) val += a.diag_add[r];
                         }
                     }
-                } else if (a.identity_pad && c == r) {
+                } else if (a.identity_pad && c == r + a.ident_shift) {
                     val = (T)1;
                 }
                 o[v] = val;
             }
         } else {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) o[v] = (a.identity_pad && (c0 + v) == r) ? (T)1 : (T)0;
+            for (int v = 0; v < VEC; ++v) o[v] = (a.identity_pad && (c0 + v) == r + a.ident_shift) ? (T)1 : (T)0;
         }
         *reinterpret_cast<vec_t*>(a.out + r * a.ldo + c0) = o;
     }
@@ -157,7 +159,7 @@ static int kmat_dispatch(algp_ctx* c, const KmatArgs<T>& a, int DP) {
 template <typename T>
 int kmat_launch(algp_ctx* c, const KmatSrc& s, const int64_t* ridx, int64_t rows, int64_t rows_pad,
                 const int64_t* cidx, int64_t cols, int64_t cols_pad, const T* diag_add, int add_noise_on_equal,
-                const int* unit, int identity_pad, T* out, int64_t ldo) {
+                const int* unit, int identity_pad, T* out, int64_t ldo, int64_t ident_shift, int64_t col_shift) {
     KmatArgs<T> a;
     a.X1 = (const T*)s.Xs;
     a.X2 = (const T*)s.Xs;
@@ -171,6 +173,8 @@ int kmat_launch(algp_ctx* c, const KmatSrc& s, const int64_t* ridx, int64_t rows
     a.same_pool = 1;
     a.unit = unit;
     a.identity_pad = identity_pad;
+    a.ident_shift = ident_shift;
+    a.col_shift = col_shift;
     a.kernel = s.kernel;
     a.outputscale = (T)s.outputscale;
     a.out = out;
@@ -178,9 +182,9 @@ int kmat_launch(algp_ctx* c, const KmatSrc& s, const int64_t* ridx, int64_t rows
     return kmat_dispatch<T>(c, a, s.DP);
 }
 template int kmat_launch<double>(algp_ctx*, const KmatSrc&, const int64_t*, int64_t, int64_t, const int64_t*, int64_t,
-                                 int64_t, const double*, int, const int*, int, double*, int64_t);
+                                 int64_t, const double*, int, const int*, int, double*, int64_t, int64_t, int64_t);
 template int kmat_launch<float>(algp_ctx*, const KmatSrc&, const int64_t*, int64_t, int64_t, const int64_t*, int64_t,
-                                int64_t, const float*, int, const int*, int, float*, int64_t);
+                                int64_t, const float*, int, const int*, int, float*, int64_t, int64_t, int64_t);
 
 template <typename T>
 int kmat_xy_launch(algp_ctx* c, const T* xs1, int64_t n1, const T* xs2, int64_t n2, int symmetric,
@@ -198,6 +202,8 @@ int kmat_xy_launch(algp_ctx* c, const T* xs1, int64_t n1, const T* xs2, int64_t 
     a.same_pool = symmetric;
     a.unit = nullptr;
     a.identity_pad = 0;
+    a.ident_shift = 0;
+    a.col_shift = 0;
     a.kernel = c->hyp.kernel;
     a.outputscale = (T)c->hyp.outputscale;
     a.out = out;

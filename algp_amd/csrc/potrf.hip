@@ -370,14 +370,17 @@ template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*
 //   inside J, 128 columns at a time: X_k <- (X_k - X_{J0:k} L_{k,J0:k}^T) inv(L_kk)^T
 template <typename T>
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                 int64_t ldl, const T* invD) {
+                 int64_t ldl, const T* invD, int64_t col_start) {
+    // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
     for (int64_t j0 = 0; j0 < npad; j0 += WB) {
         const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
+        if (j0 + w <= col_start) continue;
+        const int64_t cs = j0 > col_start ? j0 : col_start;         // first column of this block to solve
         T* Xj = X + j0;
         if (j0 > 0)
-            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, w, j0, (T)-1, X, ldx, L + j0 * ldl, ldl, (T)1, Xj, ldx, Xj, ldx,
-                                       0));
-        for (int64_t k0 = j0; k0 < j0 + w; k0 += NB) {
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, j0 + w - cs, j0, (T)-1, X, ldx, L + cs * ldl, ldl, (T)1, X + cs,
+                                       ldx, X + cs, ldx, 0));
+        for (int64_t k0 = cs; k0 < j0 + w; k0 += NB) {
             T* Xk = X + k0;
             if (k0 > j0)
                 ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, k0 - j0, (T)-1, Xj, ldx, L + k0 * ldl + j0, ldl, (T)1,
@@ -389,9 +392,9 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
     return ALGP_OK;
 }
 template int trsm_blocked<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, int64_t,
-                                  const double*);
+                                  const double*, int64_t);
 template int trsm_blocked<float>(algp_ctx*, int, float*, int64_t, int64_t, const float*, int64_t, int64_t,
-                                 const float*);
+                                 const float*, int64_t);
 
 // ---------------------------------------------------------------------------------------------
 // Vector solves (HBM-bound: each reads the lower triangle of L once).

@@ -4,6 +4,7 @@
 // agent.py:317-347 (whose M fresh factorizations collapse to one pass over V^T per pick).
 #include "common.h"
 #include "vecops.h"
+#include <algorithm>
 
 namespace algp {
 
@@ -324,6 +325,26 @@ int set_identity_launch(algp_ctx* c, T* A, int64_t npad, int64_t ld) {
 }
 template int set_identity_launch<double>(algp_ctx*, double*, int64_t, int64_t);
 template int set_identity_launch<float>(algp_ctx*, float*, int64_t, int64_t);
+
+// sum_i log L[i][i] for i < n, accumulated into *out (double)
+template <typename T>
+__global__ __launch_bounds__(256) void logdiag_kernel(const T* L, int64_t ld, int64_t n, double* out) {
+    double v = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        v += log((double)L[i * ld + i]);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
+}
+template <typename T>
+int logdiag_launch(algp_ctx* c, const T* L, int64_t ld, int64_t n, double* out) {
+    if (n <= 0) return ALGP_OK;
+    const int64_t g = std::min<int64_t>((n + 255) / 256, 64);
+    hipLaunchKernelGGL(logdiag_kernel<T>, dim3((unsigned)g), dim3(256), 0, c->cur, L, ld, n, out);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int logdiag_launch<double>(algp_ctx*, const double*, int64_t, int64_t, double*);
+template int logdiag_launch<float>(algp_ctx*, const float*, int64_t, int64_t, double*);
 
 template <typename T>
 __global__ void add_doubles_kernel(double* dst, const T* src, int64_t n) {

@@ -132,9 +132,16 @@ def main():
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--picks', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed/RCCL path even with one rank')
     ap.add_argument('--cpu-train', type=int, default=8000)
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'traffic.json'))
     args = ap.parse_args()
+
+    # stdout carries exactly ONE JSON line: libraries that write to fd 1 (RCCL prints a version banner
+    # there when the communicator is created) are sent to stderr until the result is printed.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -146,8 +153,10 @@ def main():
     import torch
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from algp_amd import _hip
@@ -164,7 +173,7 @@ def main():
     all_cand = np.arange(N, N + per * world)
     mine = all_cand[rank * per:(rank + 1) * per]
     ctx.set_candidates(mine, prior_includes_noise=True)
-    comm = TorchComm(torch.device('cuda', local_rank)) if world > 1 else LocalComm()
+    comm = TorchComm(torch.device('cuda', local_rank)) if dist is not None else LocalComm()
 
     def barrier():
         ctx.sync()
@@ -178,7 +187,7 @@ def main():
     def step():
         ctx.factorize()
         ctx.solve_candidates()
-        if world == 1:
+        if dist is None:
             picks = list(ctx.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks))
         else:
             sg = ShardedGreedy(ctx, comm, all_cand)
@@ -242,7 +251,11 @@ def main():
             out['cpu_baseline'] = cpu_baseline(w, hyp_vals, args)
         else:
             out['cpu_baseline'] = None
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(2, 1)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -97,6 +97,11 @@ int algp_set_pool_cov(algp_ctx* ctx, const void* cov, int64_t n);
  * utils.py:300 and slogdet at utils.py:193.                                                    */
 int algp_set_train(algp_ctx* ctx, const int64_t* idx, int64_t N, const void* y, const void* var);
 int algp_factorize(algp_ctx* ctx);
+/* f1: like algp_factorize, but keeps the leading 128-row blocks of the resident
+ * factor whose train rows (pool index, noise, order) and hyper-parameters are unchanged and rebuilds
+ * only the rest; appending k sites to N costs O((128+k) N^2).  kept_rows (may be NULL) reports how
+ * many rows were reused.  The reference refactorises from scratch at every step (agent.py:210).   */
+int algp_factorize_update(algp_ctx* ctx, int64_t* kept_rows);
 int algp_get_logdet(algp_ctx* ctx, double* logdet);          /* log det S                        */
 int algp_get_entropy(algp_ctx* ctx, double* H);              /* N*CONST + 1/2 log det S (utils.py:188) */
 int algp_get_alpha(algp_ctx* ctx, void* alpha_out);          /* N values                         */
@@ -117,6 +122,10 @@ int algp_get_mll_grad(algp_ctx* ctx, double* grad_out);
 int algp_set_candidates(algp_ctx* ctx, const int64_t* idx, int64_t M, int prior_includes_noise,
                         const void* extra_var);
 int algp_solve_candidates(algp_ctx* ctx);
+/* f1: like algp_solve_candidates, but keeps the columns of V^T that were solved against unchanged
+ * leading rows of the factor (same candidate list, same hyper-parameters) and solves only the
+ * trailing column blocks; alive[M] (may be NULL) disables candidates that became static-sampled.   */
+int algp_solve_candidates_update(algp_ctx* ctx, const uint8_t* alive, int64_t* kept_cols);
 int algp_get_posterior(algp_ctx* ctx, void* mu_out, void* var_out);      /* either may be NULL  */
 /* full M x M posterior covariance (utils.py:305) and mi = H(cov_xx) - H(cov) (utils.py:314);
  * cov_out / mi_out may be NULL.                                                                */

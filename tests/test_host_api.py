@@ -237,3 +237,31 @@ def test_agent_end_to_end_synthetic_field(capsys):
     args = get_args(['--eval_only', '--kernel', 'rbf', '--max_iterations', '30', '--num_runs', '3'])
     errors = demo.run_demo(args)
     assert len(errors) == 3 and all(np.isfinite(errors)) and errors[-1] < 0.2
+
+
+def test_agent_incremental_loop_equals_from_scratch():
+    """f1 in the agent: the same planning loop with and without factor reuse gives the same picks
+    and the same predictions (greedy + sampling + predict over several batches)."""
+    from algp_amd.agent import Agent
+    from algp_amd.arguments import get_args
+    from algp_amd.field import SyntheticField
+    outs = []
+    for inc in (True, False):
+        np.random.seed(3)
+        env = SyntheticField(24, 24, num_test=40)
+        args = get_args(['--eval_only', '--kernel', 'rbf', '--max_iterations', '15', '--fraction_pretrain', '0.3'])
+        args.incremental = inc
+        ag = Agent(env, args)
+        ag._setup_ipp('entropy')
+        log = []
+        for step in range(5):
+            picks = ag.greedy(4)
+            ag._add_samples(picks, [ag.static_std] * 4)
+            mob = [int(i) for i in np.random.permutation(env.num_samples)[:6]]
+            ag._add_samples(mob, [ag.mobile_std] * 6)
+            mu, var = ag.predict(return_var=True)
+            log.append((picks, mu.copy(), var.copy()))
+        outs.append(log)
+    for (p1, m1, v1), (p2, m2, v2) in zip(*outs):
+        assert p1 == p2
+        assert np.max(np.abs(m1 - m2)) < 1e-8 and np.max(np.abs(v1 - v2)) < 1e-9

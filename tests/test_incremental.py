@@ -1,0 +1,176 @@
+"""f1: incremental factor maintenance.  algp_factorize_update must give the same
+factor / alpha / log-det as a from-scratch factorisation while reusing the unchanged leading rows."""
+import numpy as np
+import pytest
+
+from algp_amd import _hip
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HYP = O.Hypers(np.log([2.5, 2.0]), np.log(1.2), np.log(0.02))
+
+
+def setup(dt=np.float64, n=2500, seed=0):
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(0, 40, (n, 2))
+    y = np.sin(X[:, 0] / 4) + np.cos(X[:, 1] / 5) + 0.1 * rng.standard_normal(n)
+    var = rng.choice([0.01, 1.0], n)
+    c = _hip.Context(dt)
+    c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+    c.set_pool(X)
+    return c, X, y, var, rng
+
+
+def fresh(X, idx, y, var, dt=np.float64):
+    c = _hip.Context(dt)
+    c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+    c.set_pool(X)
+    c.set_train(idx, y, var)
+    c.factorize()
+    out = (c.factor(), c.alpha(), c.logdet(), c.mll())
+    c.close()
+    return out
+
+
+def same(c, ref, tol=1e-10):
+    L, a, ld, mll = ref
+    assert np.max(np.abs(c.factor() - L)) < tol
+    assert np.max(np.abs(c.alpha() - a)) / np.max(np.abs(a)) < 1e-7
+    assert c.logdet() == pytest.approx(ld, rel=1e-11, abs=1e-9)
+    assert c.mll() == pytest.approx(mll, rel=1e-10)
+
+
+def test_append_reuses_leading_rows_and_matches_scratch():
+    c, X, y, var, rng = setup()
+    perm = rng.permutation(len(X))
+    idx = perm[:1000]
+    c.set_train(idx, y[idx], var[idx])
+    assert c.factorize(incremental=True) == 0               # nothing resident yet
+    # append in several steps, including crossing 128-boundaries and the allocated capacity
+    for add in (1, 50, 77, 128, 300, 700):
+        idx = np.r_[idx, perm[len(idx):len(idx) + add]]
+        c.set_train(idx, y[idx], var[idx])
+        kept = c.factorize(incremental=True)
+        assert kept == (len(idx) - add) // 128 * 128, (kept, len(idx), add)
+        same(c, fresh(X, idx, y[idx], var[idx]))
+    # the posterior built on the updated factor is right as well
+    test = perm[-200:]
+    c.set_candidates(test, prior_includes_noise=False)
+    c.solve_candidates()
+    mu, pv = c.posterior()
+    ref = O.posterior_chol(HYP, X[idx], y[idx], X[test], var[idx])
+    assert np.max(np.abs(mu - ref['mu'])) < 1e-8 and np.max(np.abs(pv - ref['var'])) < 1e-9
+    c.close()
+
+
+def test_noise_change_and_reorder_rebuild_from_the_first_changed_block():
+    c, X, y, var, rng = setup(n=1200)
+    idx = np.arange(1000)
+    c.set_train(idx, y[idx], var[idx])
+    c.factorize()
+    v2 = var[idx].copy()
+    v2[700] = 0.123                                         # re-measured site: its noise changes
+    c.set_train(idx, y[idx], v2)
+    assert c.factorize(incremental=True) == 640              # 700 // 128 * 128
+    same(c, fresh(X, idx, y[idx], v2))
+    idx2 = idx.copy()
+    idx2[[300, 301]] = idx2[[301, 300]]                      # order matters: rows are positions
+    c.set_train(idx2, y[idx2], v2[[*range(300), 301, 300, *range(302, 1000)]])
+    assert c.factorize(incremental=True) == 256
+    same(c, fresh(X, idx2, y[idx2], v2[[*range(300), 301, 300, *range(302, 1000)]]))
+    # only the targets change: everything is kept, alpha follows the new y
+    y2 = y[idx2] + 1.0
+    c.set_train(idx2, y2, v2[[*range(300), 301, 300, *range(302, 1000)]])
+    assert c.factorize(incremental=True) == 896
+    same(c, fresh(X, idx2, y2, v2[[*range(300), 301, 300, *range(302, 1000)]]))
+    # shrinking the set keeps the common prefix
+    c.set_train(idx2[:500], y2[:500], v2[[*range(300), 301, 300, *range(302, 1000)]][:500])
+    assert c.factorize(incremental=True) == 384
+    same(c, fresh(X, idx2[:500], y2[:500], v2[[*range(300), 301, 300, *range(302, 1000)]][:500]))
+    c.close()
+
+
+def test_hyper_or_pool_change_invalidates_the_factor():
+    c, X, y, var, rng = setup(n=600)
+    idx = np.arange(400)
+    c.set_train(idx, y[idx], var[idx])
+    c.factorize()
+    c.set_hypers(HYP.log_lengthscale + 0.1, HYP.log_outputscale, HYP.log_noise)
+    c.set_train(idx, y[idx], var[idx])
+    assert c.factorize(incremental=True) == 0
+    c.set_pool(X + 0.5)
+    c.set_train(idx, y[idx], var[idx])
+    assert c.factorize(incremental=True) == 0
+    c.close()
+
+
+def test_not_pd_in_the_appended_part_reports_global_pivot():
+    c, X, y, var, rng = setup(n=600)
+    idx = np.arange(300)
+    c.set_train(idx, y[idx], var[idx])
+    c.factorize()
+    idx2 = np.r_[idx, 300, 301]
+    v = np.r_[var[idx], 0.01, -50.0]                         # a negative "variance" breaks positivity
+    c.set_train(idx2, y[idx2], v)
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        c.factorize(incremental=True)
+    assert ei.value.pivot == 302
+    c.close()
+
+
+def test_fp32_append_within_tolerance():
+    c, X, y, var, rng = setup(np.float32, n=1500)
+    idx = np.arange(900)
+    c.set_train(idx, y[idx], var[idx])
+    c.factorize()
+    idx = np.arange(1100)
+    c.set_train(idx, y[idx], var[idx])
+    assert c.factorize(incremental=True) == 896
+    L, a, ld, mll = fresh(X, idx, y[idx], var[idx], np.float32)
+    assert np.max(np.abs(c.factor() - L)) < 1e-4
+    assert c.logdet() == pytest.approx(ld, rel=1e-5)
+    c.close()
+
+
+def test_candidate_solve_reuses_columns_and_matches_scratch():
+    c, X, y, var, rng = setup(n=3000)
+    perm = rng.permutation(len(X))
+    idx = perm[:900]
+    cand = np.sort(perm[900:])                               # fixed candidate list over the steps
+    static = np.zeros(len(X), bool)
+    c.set_train(idx, y[idx], np.full(len(idx), 0.01))
+    c.factorize()
+    c.set_candidates(cand, prior_includes_noise=True)
+    assert c.solve_candidates(incremental=True) == 0
+    for step in range(4):
+        picks = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4)
+        static[picks] = True
+        # the picked sites get static readings and join the train set at its END (insertion order)
+        idx = np.r_[idx, picks]
+        v = np.full(len(idx), 0.01)
+        c.set_train(idx, y[idx], v)
+        kept_rows = c.factorize(incremental=True)
+        alive = ~static[cand]
+        kept_cols = c.solve_candidates(incremental=True, alive=alive)
+        assert kept_rows == (len(idx) - 4) // 128 * 128 and kept_cols == kept_rows
+        s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        # from scratch in a new context with the static sites removed from the candidate list
+        f = _hip.Context(np.float64)
+        f.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+        f.set_pool(X)
+        f.set_train(idx, y[idx], v)
+        f.factorize()
+        f.set_candidates(cand[alive], prior_includes_noise=True)
+        f.solve_candidates()
+        want = f.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        assert np.all(np.isneginf(s[~alive]))
+        assert np.max(np.abs(s[alive] - want)) < 1e-10
+        mu, pv = c.posterior()
+        mu2, pv2 = f.posterior()
+        assert np.max(np.abs(mu[alive] - mu2)) < 1e-9 and np.max(np.abs(pv[alive] - pv2)) < 1e-10
+        f.close()
+    # a different candidate list cannot reuse anything
+    c.set_candidates(cand[:-1], prior_includes_noise=True)
+    assert c.solve_candidates(incremental=True) == 0
+    c.close()
