@@ -47,6 +47,7 @@ SIGNATURES = {
     'algp_set_candidates': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_int, C.c_void_p]),
     'algp_solve_candidates': (C.c_int, [_c_ctx]),
     'algp_solve_candidates_update': (C.c_int, [_c_ctx, C.c_void_p, _i64p]),
+    'algp_set_candidate_alive': (C.c_int, [_c_ctx, C.c_void_p]),
     'algp_get_posterior': (C.c_int, [_c_ctx, C.c_void_p, C.c_void_p]),
     'algp_get_posterior_cov': (C.c_int, [_c_ctx, C.c_void_p, _dblp]),
     'algp_posterior_mean': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p]),
@@ -249,12 +250,14 @@ class Context(object):
 
     def solve_candidates(self, incremental=False, alive=None):
         """incremental=True keeps the V^T columns that are still valid (returns how many columns)."""
-        if not incremental and alive is None:
-            self._check(self.lib.algp_solve_candidates(self.h))
-            return 0
         a = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint8)
         if a is not None and a.shape != (self.M,):
             raise ValueError('alive must have one entry per candidate')
+        if not incremental:
+            self._check(self.lib.algp_solve_candidates(self.h))
+            if a is not None:
+                self._check(self.lib.algp_set_candidate_alive(self.h, _ptr(a)))
+            return 0
         kept = C.c_int64()
         self._check(self.lib.algp_solve_candidates_update(self.h, _ptr(a), C.byref(kept)))
         return kept.value

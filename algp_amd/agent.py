@@ -273,14 +273,24 @@ class Agent(object):
         static, mobile0 = self._masks()
         static = static.copy()
         static[static_indices] = True
+        base = self._train_order(static | mobile0)          # sites sampled whichever path is taken
+        in_base = np.zeros(n, bool)
+        in_base[base] = True
         utilities = []
         for path in paths_mobile_indices:
             mobile = mobile0.copy()
             mobile[path] = True
             sampled = static | mobile
-            A = np.where(sampled)[0]
+            # f3: the path's new sites are appended behind the common base, so consecutive paths share
+            # the leading rows of the factor and only the appended block is re-factorised (the block
+            # determinant lemma, done by algp_factorize_update); a base site whose fused noise changes
+            # because the path re-measures it limits the reuse to the rows before it.
+            extra = [int(i) for i in dict.fromkeys(int(j) for j in path) if not in_base[i]]
+            A = np.r_[base, np.array(extra, dtype=np.int64)] if extra else base
             var = self._fused_var(static[A], mobile[A])
-            ut = c.set_entropy(A, var)
+            c.set_train(A, np.zeros(len(A)), var)
+            c.factorize(incremental=True)
+            ut = c.entropy()
             if self.criterion == 'mutual_information':
                 ut += c.set_entropy(np.where(~sampled)[0])            # H(C_AbarAbar), no measurement noise
                 var_all = np.zeros(n)

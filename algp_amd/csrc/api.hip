@@ -411,6 +411,23 @@ struct Impl {
             while (p0 < lim && c->vt_fact_idx[p0] == c->fact_idx[p0] && c->vt_fact_var[p0] == c->fact_var[p0]) ++p0;
             keep = p0 / NB * NB;
         }
+        // candidate kinds under the current train set
+        std::vector<int> kind(Mpad, -1);
+        if (c->prior_noise)
+            for (int64_t j = 0; j < M; ++j) kind[j] = (int)c->pos_in_train[c->cand_idx[j]];
+        std::vector<int64_t> became_unit;
+        if (keep > 0) {
+            // a kept column block is only valid for a row whose right-hand side is unchanged:
+            //  - ordinary -> unit row e_pos with pos >= keep: the solution is zero before pos: zero the kept part;
+            //  - anything else that changed: give up the reuse.
+            for (int64_t j = 0; j < M && keep > 0; ++j) {
+                const int was = c->vt_kind[j], now = kind[j];
+                if (was == now) continue;
+                if (was < 0 && now >= keep) became_unit.push_back(j);
+                else if (!(was >= keep && now >= keep)) keep = 0;      // unit rows beyond `keep` are rebuilt anyway
+            }
+            if (keep == 0) became_unit.clear();
+        }
         c->solved = false;
         if (!c->Vt.p || c->ldv_cap < ldv || (keep == 0 && c->ldv_cap != ldv) || c->Vt.cap < sizeof(T) * Mpad * c->ldv_cap) {
             // (re)allocate; keep the valid columns when growing
@@ -439,11 +456,10 @@ struct Impl {
         {
             // greedy semantics: a candidate that is a train site is the unit vector e_pos (its
             // noise changes); predictive semantics: it is an ordinary point at the same location
-            std::vector<int> kind(Mpad, -1);
-            if (c->prior_noise)
-                for (int64_t j = 0; j < M; ++j) kind[j] = (int)c->pos_in_train[c->cand_idx[j]];
             ALGP_TRY(ensure(c, c->ckind, sizeof(int) * Mpad));
             ALGP_HIP(hipMemcpyAsync(c->ckind.p, kind.data(), sizeof(int) * Mpad, hipMemcpyHostToDevice, c->stream));
+            for (int64_t j : became_unit)
+                ALGP_HIP(hipMemsetAsync(p(c->Vt) + j * ldc, 0, sizeof(T) * keep, c->stream));
             ALGP_TRY(sync(c));
         }
         KmatSrc s = make_src(c);
@@ -469,6 +485,7 @@ struct Impl {
         c->vt_fact_idx = c->fact_idx;
         c->vt_fact_var = c->fact_var;
         c->vt_cand_idx = c->cand_idx;
+        c->vt_kind.assign(kind.begin(), kind.begin() + M);
         c->vt_hyp_stamp = c->hyp_stamp;
         c->vt_prior_noise = c->prior_noise;
         c->vt_has_extra = c->cextra.p != nullptr;
@@ -1100,6 +1117,13 @@ int algp_solve_candidates_update(algp_ctx* c, const uint8_t* alive, int64_t* kep
     if (kept_cols) *kept_cols = rc == ALGP_OK ? c->kept_cols_last : 0;
     if (c->prof_on) prof_collect(c);
     return rc;
+}
+int algp_set_candidate_alive(algp_ctx* c, const uint8_t* alive) {
+    CHECK_CTX(c);
+    if (!c->solved || !alive) return fail(c, ALGP_ERR_STATE, "set_candidate_alive: solve the candidates first");
+    if (hipMemcpyAsync(c->alive.p, alive, c->M, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return fail(c, ALGP_ERR_HIP, "set_candidate_alive: copy failed");
+    return sync(c);
 }
 int algp_get_posterior(algp_ctx* c, void* mu, void* var) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_posterior(c, mu, var))); }
 int algp_get_posterior_cov(algp_ctx* c, void* cov, double* mi) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_posterior_cov(c, cov, mi))); }

@@ -95,6 +95,7 @@ struct algp_ctx {
     // what the resident V^T columns were solved for (incremental candidate solve)
     std::vector<int64_t> vt_fact_idx, vt_cand_idx;
     std::vector<double> vt_fact_var;
+    std::vector<int> vt_kind;            // per candidate: position in the train set it was solved as, or -1
     uint64_t vt_hyp_stamp = 0;
     int vt_prior_noise = -1;
     bool vt_has_extra = false;

@@ -126,6 +126,8 @@ int algp_solve_candidates(algp_ctx* ctx);
  * leading rows of the factor (same candidate list, same hyper-parameters) and solves only the
  * trailing column blocks; alive[M] (may be NULL) disables candidates that became static-sampled.   */
 int algp_solve_candidates_update(algp_ctx* ctx, const uint8_t* alive, int64_t* kept_cols);
+/* disable / enable candidates after a solve (alive[M] bytes; 0 = scored as -inf, agent.py:318)      */
+int algp_set_candidate_alive(algp_ctx* ctx, const uint8_t* alive);
 int algp_get_posterior(algp_ctx* ctx, void* mu_out, void* var_out);      /* either may be NULL  */
 /* full M x M posterior covariance (utils.py:305) and mi = H(cov_xx) - H(cov) (utils.py:314);
  * cov_out / mi_out may be NULL.                                                                */

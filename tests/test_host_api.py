@@ -265,3 +265,17 @@ def test_agent_incremental_loop_equals_from_scratch():
     for (p1, m1, v1), (p2, m2, v2) in zip(*outs):
         assert p1 == p2
         assert np.max(np.abs(m1 - m2)) < 1e-8 and np.max(np.abs(v1 - v2)) < 1e-9
+
+
+def test_best_path_many_paths_vs_oracle_and_reuse(golden):
+    """f3: path utilities through the incremental factor equal one fresh slogdet per path."""
+    g = golden('g4_best_path')
+    rng = np.random.RandomState(2)
+    n = len(g['g4_cov'])
+    paths = [[int(i) for i in rng.permutation(n)[:rng.randint(5, 14)]] for _ in range(25)]
+    sd, md = _state_lists(g['g4_static'], g['g4_mobile'])
+    si = [int(v) for v in g['g4_static_indices']]
+    for crit in ('entropy', 'mutual_information'):
+        a = _agent(g['g4_cov'].astype(np.float64), sd, md, crit)
+        idx, ut = O.best_path_ref(g['g4_cov'], g['g4_static'], g['g4_mobile'], paths, si, 0.1, 1.0, crit)
+        assert a.best_path(paths, si) == idx

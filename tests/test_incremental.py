@@ -139,21 +139,24 @@ def test_candidate_solve_reuses_columns_and_matches_scratch():
     idx = perm[:900]
     cand = np.sort(perm[900:])                               # fixed candidate list over the steps
     static = np.zeros(len(X), bool)
-    c.set_train(idx, y[idx], np.full(len(idx), 0.01))
+    v = np.full(len(idx), 0.01)
+    c.set_train(idx, y[idx], v)
     c.factorize()
     c.set_candidates(cand, prior_includes_noise=True)
     assert c.solve_candidates(incremental=True) == 0
     for step in range(4):
         picks = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4)
         static[picks] = True
-        # the picked sites get static readings and join the train set at its END (insertion order)
-        idx = np.r_[idx, picks]
-        v = np.full(len(idx), 0.01)
+        # the picked sites get static readings and join the train set at its END (insertion order);
+        # a few more candidates get MOBILE readings: they stay candidates but turn into unit rows
+        mob = [int(m) for m in cand[rng.permutation(len(cand))[:5]] if m not in idx and m not in picks]
+        idx = np.r_[idx, picks, mob].astype(np.int64)
+        v = np.r_[v if step else np.full(900, 0.01), np.full(4, 0.01), np.full(len(mob), 1.0)]
         c.set_train(idx, y[idx], v)
         kept_rows = c.factorize(incremental=True)
         alive = ~static[cand]
         kept_cols = c.solve_candidates(incremental=True, alive=alive)
-        assert kept_rows == (len(idx) - 4) // 128 * 128 and kept_cols == kept_rows
+        assert kept_rows == (len(idx) - 4 - len(mob)) // 128 * 128 and kept_cols == kept_rows
         s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
         # from scratch in a new context with the static sites removed from the candidate list
         f = _hip.Context(np.float64)
@@ -164,7 +167,7 @@ def test_candidate_solve_reuses_columns_and_matches_scratch():
         f.set_candidates(cand[alive], prior_includes_noise=True)
         f.solve_candidates()
         want = f.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
-        assert np.all(np.isneginf(s[~alive]))
+        assert np.all(np.isneginf(s[~alive])) and not np.any(np.isnan(s))
         assert np.max(np.abs(s[alive] - want)) < 1e-10
         mu, pv = c.posterior()
         mu2, pv2 = f.posterior()
