@@ -15,7 +15,7 @@ F32, F64 = 0, 1
 KERNEL_RBF, KERNEL_MATERN15 = 0, 1
 CRIT_ENTROPY, CRIT_MUTUAL_INFORMATION = 0, 1
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_OOM, ERR_STATE, ERR_NO_DEVICE = range(7)
-PROF = dict(kmat=0, gemm_chol=1, gemm_trsm=2, potrf_diag=3, trsv=4, rows=5, score=6, gemm_other=7, cholesky=8)
+PROF = dict(kmat=0, gemm_chol=1, gemm_trsm=2, potrf_diag=3, trsv=4, rows=5, score=6, gemm_other=7, cholesky=8, trsm=9)
 
 _c_ctx = C.c_void_p
 _i64p = C.POINTER(C.c_int64)
@@ -38,6 +38,7 @@ SIGNATURES = {
     'algp_set_train': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p, C.c_void_p]),
     'algp_factorize': (C.c_int, [_c_ctx]),
     'algp_factorize_update': (C.c_int, [_c_ctx, _i64p]),
+    'algp_fit_and_solve': (C.c_int, [_c_ctx]),
     'algp_get_logdet': (C.c_int, [_c_ctx, _dblp]),
     'algp_get_entropy': (C.c_int, [_c_ctx, _dblp]),
     'algp_get_alpha': (C.c_int, [_c_ctx, C.c_void_p]),
@@ -210,6 +211,10 @@ class Context(object):
         kept = C.c_int64()
         self._check(self.lib.algp_factorize_update(self.h, C.byref(kept)))
         return kept.value
+
+    def fit_and_solve(self):
+        """factorize() + solve_candidates() as one overlapped pipeline."""
+        self._check(self.lib.algp_fit_and_solve(self.h))
 
     def _get_double(self, fn):
         v = C.c_double()

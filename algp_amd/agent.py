@@ -384,6 +384,57 @@ class Agent(object):
         print('Strategy: {:s}  final test ERROR: {:.4f}'.format(strategy, error))
         return {'mean': pred, 'error': [error]}
 
+    def run_naive(self, std, counts, metric='distance'):
+        """Lawn-mower baselines 'Naive Static' / 'Naive Mobile' (agent.py:405-473): sweep the rows back
+        and forth, sampling every field cell passed with noise `std`; after each leg of `counts`
+        ('distance': cells moved, 'samples': readings taken) predict the held-out set with its
+        covariance and mutual information."""
+        rows = self.env.map.shape[0]
+        errors, mis, mean_vars = [], [], []
+        mu = cov = None
+        for ns in counts:
+            inds, moved = [], 0
+            while True:
+                nxt = (self.pose[0] + self.heading[0], self.pose[1] + self.heading[1])
+                gi = self.env.map_pose_to_gp_index_matrix[nxt]
+                if gi is not None:
+                    inds.append(gi)
+                if metric == 'samples':
+                    if nxt[0] in (0, rows - 1):
+                        # end of a row: step two columns over and turn around
+                        back = nxt[0] - 1 if nxt[0] == rows - 1 else nxt[0] + 1
+                        hop = [nxt, (nxt[0], nxt[1] + 1), (nxt[0], nxt[1] + 2), (back, nxt[1] + 2)]
+                        self.path = np.concatenate([self.path, hop], axis=0).astype(int)
+                        self.heading = (-self.heading[0], 0)
+                        self.pose = hop[-1]
+                    else:
+                        self.path = np.concatenate([self.path, [nxt]], axis=0).astype(int)
+                        self.pose = nxt
+                    if len(inds) == ns:
+                        break
+                elif metric == 'distance':
+                    moved += 1
+                    self.path = np.concatenate([self.path, [nxt]], axis=0).astype(int)
+                    if nxt[1] % 2 == 0 and nxt[0] == 0:
+                        self.heading = (0, 1) if self.heading == (-1, 0) else (1, 0)
+                    elif nxt[1] % 2 == 0 and nxt[0] == rows - 1:
+                        self.heading = (0, 1) if self.heading == (1, 0) else (-1, 0)
+                    self.pose = nxt
+                    if moved == ns:
+                        break
+                else:
+                    raise NotImplementedError
+            self._add_samples(inds, [std] * len(inds))
+            mu, cov, mi = self.predict(return_cov=True, return_mi=True)
+            errors.append(compute_mae(self.env.test_Y, mu))
+            mis.append(mi)
+            mean_vars.append(np.diag(cov).mean())
+        var = np.diag(cov)
+        print('Strategy: ', 'Naive Static' if std == self.static_std else 'Naive Mobile')
+        print('Test ERROR: {:.4f}  predictive variance max {:.3f} min {:.3f} mean {:.3f}'.format(
+            errors[-1], var.max(), var.min(), var.mean()))
+        return {'mean': mu, 'error': errors, 'mi': mis, 'mean_var': mean_vars}
+
     def prediction_vs_distance(self, test_every, num_runs):
         errors, mis, mean_vars, mu = [], [], [], None
         for r in range(1, num_runs + 1):

@@ -51,7 +51,13 @@ struct algp_ctx {
     int dtype = ALGP_F64;
     size_t es = 8;
     hipStream_t stream = nullptr;    // main stream (all results are complete on it before an ABI call returns)
-    hipStream_t stream2 = nullptr;   // second stream (reserved for overlapped panel work; unused in round 1)
+    hipStream_t stream2 = nullptr;   // helper streams: independent row chunks of the candidate solve overlap on them
+    hipStream_t stream3 = nullptr, stream4 = nullptr;
+    int trsm_chunks = 3;
+    hipStream_t streamC = nullptr;   // high-priority stream: the factorisation inside algp_fit_and_solve
+    bool record_blk_events = false;  // cholesky_blocked records one event per factored 512-column block ...
+    bool gate_blk_events = false;    // ... and the candidate solve waits for block J's event before touching it
+    size_t blk_event_base = 16;
     hipStream_t cur = nullptr;       // stream the launch helpers currently target
     std::vector<hipEvent_t> sync_events;
     std::string err;
@@ -122,6 +128,9 @@ void prof_collect(algp_ctx* c);
 // un-nested wall-time span on the main stream (e.g. a whole factorisation that overlaps two streams)
 void prof_span_begin(algp_ctx* c, int klass, double flops, double bytes);
 void prof_span_end(algp_ctx* c);
+void prof_span_end_on(algp_ctx* c, hipStream_t st);
+void prof_span_begin2(algp_ctx* c, int klass, double flops, double bytes);   // second span, starts on c->cur
+void prof_span_end2(algp_ctx* c);
 
 #define ALGP_HIP(call)                                                                          \
     do {                                                                                        \

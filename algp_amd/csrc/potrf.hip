@@ -49,32 +49,44 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
 
 // ---------------------------------------------------------------------------------------------
 // Diagonal block: factor + invert a 128 x 128 SPD block inside one 256-thread workgroup's LDS.
-//   S[128][129] holds the block (one element of padding per row: column walks hit distinct banks).
+//
+// LDS image: only the lower block triangle, as 36 blocks of 16 x 16 with row stride 17
+// (78 KB fp64 / 39 KB fp32): the kernel fits beside one 64 KB GEMM workgroup on a CU, so it can
+// start while a GEMM saturates the chip.  LB(i, j) addresses element (i, j), block(j) <= block(i);
+// inside a diagonal block the strict upper part is free and holds the transposed inverse.
 //   Factor, 16 columns at a time (8 panels):
-//     - LDL-style column sweep restricted to the panel: for column j with pivot d_j = S[j][j],
-//       S[i][k] -= S[i][j] S[k][j] / d_j for j < k < panel end, k <= i   (one barrier per column,
-//       but only 16 columns wide and 4 waves deep);
-//     - scale the panel: L[i][c] = S[i][c] / sqrt(d_c);
-//     - rank-16 update of everything right of the panel with 4 x 4 register tiles (one barrier).
-//   Inverse X = L^-1 by 16 x 16 blocks: the 8 diagonal blocks by per-column substitution (no
-//   barrier), then block row I: T = sum_K L_IK X_KJ for all J < I, X_IJ = -X_II T (two barriers).
-//   X[a][b] (a > b) is kept transposed in the free strict upper triangle, S[b][a]; X[a][a] = dinv[a].
+//     - panel sweep: thread r owns row k0+r of the panel in registers; the pivot column is gathered
+//       into a double-buffered LDS line (one barrier per column, reciprocal by Newton steps);
+//     - scale the panel: L[i][c] = a[c] / sqrt(d_c);
+//     - rank-16 update of the blocks right of the panel on the matrix cores (4 MFMAs per block).
+//   Inverse X = L^-1 by 16 x 16 blocks: diagonal blocks by per-column substitution, then block row I:
+//     T = sum_K L_IK X_KJ, X_IJ = -X_II T for all J < I on the matrix cores (the accumulator of T is
+//     the B operand of the second product); after a barrier X_IJ overwrites L_IJ, which no later
+//     block row needs.
 // ---------------------------------------------------------------------------------------------
+constexpr int DBS = 16 * 17;                                   // elements per stored block
+__device__ __forceinline__ int LB(int i, int j) {
+    const int I = i >> 4, J = j >> 4;
+    return (I * (I + 1) / 2 + J) * DBS + (i & 15) * 17 + (j & 15);
+}
+
 template <typename T, bool FACTOR>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* inv_out, double* logdet_acc,
                                                           int* info, int64_t block_row0) {
-    __shared__ T S[128 * 129];
+    __shared__ T S[36 * DBS];
     __shared__ T dd[128];
     __shared__ T dinv[128];
     __shared__ double red[4];
     __shared__ T prow[2 * 18];
     __shared__ int bad;
+    using F = MF<T>;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     ALGP_STAMP(0);
     if (tid == 0) bad = 0;
     {
         // block load: 16-byte vectors, 8 loads in flight per thread (a load-per-iteration loop
-        // serialises 64 memory round trips and alone costs >100 us)
+        // serialises 64 memory round trips and alone costs >100 us); only block(j) <= block(i) is kept
         constexpr int VEC = 16 / sizeof(T);
         typedef T vec_t __attribute__((ext_vector_type(VEC)));
         constexpr int VPR = 128 / VEC;                  // vectors per row
@@ -90,8 +102,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int v = tid + 256 * (b0 + u);
+                const int i = v / VPR, j = (v % VPR) * VEC;
+                if ((j >> 4) <= (i >> 4)) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) S[(v / VPR) * 129 + (v % VPR) * VEC + e] = tmp[u][e];
+                    for (int e = 0; e < VEC; ++e) S[LB(i, j + e)] = tmp[u][e];
+                }
             }
         }
     }
@@ -102,13 +117,12 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
         for (int k0 = 0; k0 < 128; k0 += 16) {
             const int k1 = k0 + 16;
             if (k0 == 0) ALGP_STAMP(2);
-            // ---- panel sweep: thread `rowid` owns row k0+rowid of the panel in registers; the pivot
-            //      row travels through a double-buffered LDS line: one barrier per column ----
-            const int rowid = tid;                       // threads >= 128-k0 idle here
+            const int rowid = tid;                       // threads >= 128-k0 idle in the sweep
             const bool active = rowid < 128 - k0;
+            const int myrow = active ? LB(k0 + rowid, k0) : 0;
             T a[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = active ? S[(k0 + rowid) * 129 + k0 + c] : (T)0;
+            for (int c = 0; c < 16; ++c) a[c] = active ? S[myrow + c] : (T)0;
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) {
                 T* line = prow + (jj & 1) * 18;
@@ -128,7 +142,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
                     for (int c = jj + 1; c < 16; ++c) a[c] -= ci * line[c];
                 }
             }
-            // ---- write the scaled panel back: L[i][c] = a[c] / sqrt(d_c) ----
             __syncthreads();                             // dd[k0..k1) complete
             if (tid < 16) dinv[k0 + tid] = fast_rsqrt(dd[k0 + tid]);
             __syncthreads();
@@ -137,39 +150,33 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
                 const int i = k0 + rowid;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    if (i > k0 + c) S[i * 129 + k0 + c] = a[c] * dinv[k0 + c];
-                    else if (i == k0 + c) S[i * 129 + i] = dd[i] * dinv[i];        // sqrt(d) = d / sqrt(d)
+                    if (i > k0 + c) S[myrow + c] = a[c] * dinv[k0 + c];
+                    else if (i == k0 + c) S[myrow + c] = dd[i] * dinv[i];          // sqrt(d) = d / sqrt(d)
                 }
             }
             __syncthreads();
             if (k0 == 0) ALGP_STAMP(4);
-            // ---- rank-16 update of everything right of the panel on the matrix cores: one 16 x 16
-            //      output tile = 4 MFMAs (K = 16); operands are 16 consecutive rows at one column
-            //      (row stride 129: conflict free); C tiles are read-modify-written in the C layout ----
+            // ---- rank-16 update of the blocks right of the panel: block (K1+ti, K1+tk) -= P_ti P_tk^T ----
             const int r = 128 - k1;
             if (r > 0) {
-                using F = MF<T>;
-                const int lane = tid & 63, wave = tid >> 6;
+                const int K0 = k0 >> 4, K1 = k1 >> 4;
                 const int nb16 = r >> 4, ntile16 = nb16 * (nb16 + 1) / 2;
                 for (int t = wave; t < ntile16; t += 4) {
                     int ti = 0;
                     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
                     const int tk = t - ti * (ti + 1) / 2;
-                    const int i0 = k1 + 16 * ti, c0 = k1 + 16 * tk;
+                    const int bi = K1 + ti, bk = K1 + tk;
+                    const T* Pa = S + (bi * (bi + 1) / 2 + K0) * DBS;
+                    const T* Pb = S + (bk * (bk + 1) / 2 + K0) * DBS;
+                    T* Cb = S + (bi * (bi + 1) / 2 + bk) * DBS;
                     typename F::acc_t acc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = (T)0;
 #pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        const T av = S[(i0 + (lane & 15)) * 129 + k0 + 4 * st + (lane >> 4)];
-                        const T bv = S[(c0 + (lane & 15)) * 129 + k0 + 4 * st + (lane >> 4)];
-                        acc = F::mfma(av, bv, acc);
-                    }
+                    for (int st = 0; st < 4; ++st)
+                        acc = F::mfma(Pa[li * 17 + 4 * st + lg], Pb[li * 17 + 4 * st + lg], acc);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        T* dst = S + (i0 + F::row_of(lane, q)) * 129 + c0 + (lane & 15);
-                        *dst -= acc[q];
-                    }
+                    for (int q = 0; q < 4; ++q) Cb[F::row_of(lane, q) * 17 + li] -= acc[q];
                 }
                 __syncthreads();
                 if (k0 == 0) ALGP_STAMP(5);
@@ -188,17 +195,19 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
         }
         for (int e = tid; e < 128 * 128; e += 256) {
             const int i = e >> 7, j = e & 127;
-            if (j <= i) A[(int64_t)i * lda + j] = S[i * 129 + j];
+            if (j <= i) A[(int64_t)i * lda + j] = S[LB(i, j)];
         }
     } else {
-        if (tid < 128) dinv[tid] = (T)1 / S[tid * 129 + tid];
+        if (tid < 128) dinv[tid] = (T)1 / S[LB(tid, tid)];
     }
     __syncthreads();
     ALGP_STAMP(7);
 
-    // ---- inverse: diagonal 16 x 16 blocks, one column per thread, values kept in registers ----
+    // ---- inverse of the diagonal 16 x 16 blocks: one column per thread, values kept in registers;
+    //      X_II[i][c] (i > c) goes to the free upper part of the block, position (c, i) ----
     if (tid < 128) {
-        const int base = (tid >> 4) * 16, c = tid & 15;
+        const int I = tid >> 4, c = tid & 15, base = I * 16;
+        T* Db = S + (I * (I + 1) / 2 + I) * DBS;
         T x[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) x[i] = (T)0;
@@ -209,74 +218,84 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
                 T sum = (T)0;
 #pragma unroll
                 for (int k = 0; k < i; ++k)
-                    if (k >= c) sum += S[(base + i) * 129 + base + k] * x[k];
+                    if (k >= c) sum += Db[i * 17 + k] * x[k];
                 x[i] = -sum * dinv[base + i];
             }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (i > c) S[(base + c) * 129 + base + i] = x[i];
+            if (i > c) Db[c * 17 + i] = x[i];
     }
     __syncthreads();
     ALGP_STAMP(8);
-    // ---- block rows 1..7 on the matrix cores.  For block (I, J), J < I:
-    //        T    = sum_{K=J}^{I-1} L_IK X_KJ      (A = L_IK rows r0+m; B[k][b] = X_KJ[k][b] = S[16J+b][16K+k])
-    //        X_IJ = -X_II T                          (A = X_II; B = T straight from the accumulator: for the
-    //                                                 k-step s the lane's register s IS row k of T in its column)
-    //      X_JJ / X_II are lower triangular with the diagonal in dinv and zeros above. ----
-    {
-        using F = MF<T>;
-        const int lane = tid & 63, wave = tid >> 6;
-        const int li = lane & 15, lg = lane >> 4;
-        for (int I = 1; I < 8; ++I) {
-            const int r0 = 16 * I;
-            for (int J = wave; J < I; J += 4) {
-                const int b0 = 16 * J;
+    // ---- block rows 1..7 on the matrix cores ----
+    for (int I = 1; I < 8; ++I) {
+        const int r0 = 16 * I;
+        const T* Dii = S + (I * (I + 1) / 2 + I) * DBS;
+        typename F::acc_t outs[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int J = wave + 4 * u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) outs[u][q] = (T)0;
+            if (J < I) {
                 typename F::acc_t acc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = (T)0;
-                // K = J: X_JJ[k][b] for k >= b only
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const int k = 4 * st + lg;                        // row of X_JJ, b = li its column
-                    const T av = S[(r0 + li) * 129 + b0 + k];
-                    T bv = (T)0;
-                    if (k > li) bv = S[(b0 + li) * 129 + b0 + k];
-                    else if (k == li) bv = dinv[b0 + li];
-                    acc = F::mfma(av, bv, acc);
-                }
-                for (int K = J + 1; K < I; ++K) {
+                // K = J: B[k][b] = X_JJ[k][b] = (k > b) ? Djj(b, k) : (k == b ? dinv : 0)
+                {
+                    const T* Lik = S + (I * (I + 1) / 2 + J) * DBS;
+                    const T* Djj = S + (J * (J + 1) / 2 + J) * DBS;
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
-                        const int k = 16 * K + 4 * st + lg;
-                        acc = F::mfma(S[(r0 + li) * 129 + k], S[(b0 + li) * 129 + k], acc);
+                        const int k = 4 * st + lg;
+                        T bv = (T)0;
+                        if (k > li) bv = Djj[li * 17 + k];
+                        else if (k == li) bv = dinv[16 * J + li];
+                        acc = F::mfma(Lik[li * 17 + k], bv, acc);
                     }
                 }
-                // X_IJ = -X_II T : k-step s pairs A[m'][k] with the accumulator register s, whose row is
-                // row_of(lane, s); A[m' = li][k] = X_II[li][k] = S[r0+k][r0+li] (k < li), dinv (k == li), 0 (k > li)
-                typename F::acc_t out;
+                for (int K = J + 1; K < I; ++K) {
+                    const T* Lik = S + (I * (I + 1) / 2 + K) * DBS;
+                    const T* Xkj = S + (K * (K + 1) / 2 + J) * DBS;          // row-major X_KJ[k][b]
 #pragma unroll
-                for (int q = 0; q < 4; ++q) out[q] = (T)0;
+                    for (int st = 0; st < 4; ++st) {
+                        const int k = 4 * st + lg;
+                        acc = F::mfma(Lik[li * 17 + k], Xkj[k * 17 + li], acc);
+                    }
+                }
+                // X_IJ = -X_II T: k-step st pairs A[m'][k] with accumulator register st (row k = row_of(lane, st))
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     const int k = F::row_of(lane, st);
                     T av = (T)0;
-                    if (k < li) av = S[(r0 + k) * 129 + r0 + li];
+                    if (k < li) av = Dii[k * 17 + li];
                     else if (k == li) av = dinv[r0 + li];
-                    out = F::mfma(av, acc[st], out);
+                    outs[u] = F::mfma(av, acc[st], outs[u]);
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) S[(b0 + li) * 129 + r0 + F::row_of(lane, q)] = -out[q];
             }
-            __syncthreads();
-            ALGP_STAMP(9 + I);
         }
+        __syncthreads();                                  // every wave has finished reading L_I*
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int J = wave + 4 * u;
+            if (J < I) {
+                T* Xij = S + (I * (I + 1) / 2 + J) * DBS;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Xij[F::row_of(lane, q) * 17 + li] = -outs[u][q];
+            }
+        }
+        __syncthreads();
+        ALGP_STAMP(9 + I);
     }
     for (int e = tid; e < 128 * 128; e += 256) {
         const int i = e >> 7, j = e & 127;
         T v = (T)0;
-        if (j < i) v = S[j * 129 + i];
-        else if (j == i) v = dinv[i];
+        if ((j >> 4) < (i >> 4)) v = S[LB(i, j)];
+        else if ((j >> 4) == (i >> 4)) {
+            if (j < i) v = S[LB(i, i) - (i & 15) * 17 - (i & 15) + (j & 15) * 17 + (i & 15)];   // upper, transposed: (j, i)
+            else if (j == i) v = dinv[i];
+        }
         inv_out[i * 128 + j] = v;
     }
     ALGP_STAMP(17);
@@ -313,6 +332,8 @@ template int trinv_diag_launch<float>(algp_ctx*, const float*, int64_t, float*);
 // tiles share each A row-panel through the XCD's L2 (TRSM).
 // ---------------------------------------------------------------------------------------------
 constexpr int WB = 512;
+
+static hipEvent_t sync_event(algp_ctx* c, size_t i);
 
 // factor block column [j0, j0+w) over all rows >= j0, 128 columns at a time (launches go to c->cur)
 template <typename T>
@@ -351,6 +372,9 @@ int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doubl
     for (int64_t j0 = 0; j0 < npad; j0 += WB) {
         const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
         ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, j0, w));
+        // rows [j0, j0+w) of L and their inverse diagonal blocks are final: a pipelined candidate solve
+        // (algp_fit_and_solve) may start on column block j0/WB
+        if (c->record_blk_events) ALGP_HIP(hipEventRecord(sync_event(c, c->blk_event_base + (size_t)(j0 / WB)), c->cur));
         const int64_t mrem = npad - (j0 + w);
         if (mrem > 0) {
             // trailing update with the whole block: A22 -= P_blk P_blk^T, K = w, lower tiles
@@ -369,12 +393,13 @@ template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*
 //   X_J <- X_J - X_{0:J} L_{J,0:J}^T            (one GEMM, n = 512)
 //   inside J, 128 columns at a time: X_k <- (X_k - X_{J0:k} L_{k,J0:k}^T) inv(L_kk)^T
 template <typename T>
-int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                 int64_t ldl, const T* invD, int64_t col_start) {
+static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
+                     int64_t ldl, const T* invD, int64_t col_start) {
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
     for (int64_t j0 = 0; j0 < npad; j0 += WB) {
         const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
         if (j0 + w <= col_start) continue;
+        if (c->gate_blk_events) ALGP_HIP(hipStreamWaitEvent(c->cur, sync_event(c, c->blk_event_base + (size_t)(j0 / WB)), 0));
         const int64_t cs = j0 > col_start ? j0 : col_start;         // first column of this block to solve
         T* Xj = X + j0;
         if (j0 > 0)
@@ -390,6 +415,47 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
         }
     }
     return ALGP_OK;
+}
+
+static hipEvent_t sync_event(algp_ctx* c, size_t i) {
+    while (c->sync_events.size() <= i) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        c->sync_events.push_back(e);
+    }
+    return c->sync_events[i];
+}
+
+// The rows of X (candidates) are independent, so a tall X is solved as two halves on two streams:
+// the tail of every big GEMM of one half (3128 workgroups over 512 resident slots leave the last
+// round at 11 % occupancy) and its short HBM-bound in-block launches run beside the other half's
+// MFMA-bound GEMMs.
+template <typename T>
+int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
+                 int64_t ldl, const T* invD, int64_t col_start) {
+    const int64_t tiles = mpad / NB;
+    hipStream_t streams[4] = {c->stream, c->stream2, c->stream3, c->stream4};
+    int nch = c->trsm_chunks < 1 ? 1 : (c->trsm_chunks > 4 ? 4 : c->trsm_chunks);
+    while (nch > 1 && (!streams[nch - 1] || tiles < 32 * nch)) --nch;
+    if (nch == 1 || c->cur != c->stream)
+        return trsm_rows<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start);
+    ALGP_HIP(hipEventRecord(sync_event(c, 0), streams[0]));
+    int rc = ALGP_OK;
+    int64_t r0 = 0;
+    for (int k = nch - 1; k >= 0; --k) {                       // helper streams first, the main stream last
+        const int64_t rows = (k == 0) ? mpad - r0 : (tiles / nch) * NB;
+        if (k > 0) ALGP_HIP(hipStreamWaitEvent(streams[k], sync_event(c, 0), 0));
+        c->cur = streams[k];
+        if (rc == ALGP_OK) rc = trsm_rows<T>(c, klass, X + r0 * ldx, rows, ldx, L, npad, ldl, invD, col_start);
+        r0 += rows;
+    }
+    c->cur = streams[0];
+    // the main stream continues only after every chunk is done (also on the error path)
+    for (int k = 1; k < nch; ++k) {
+        hipEventRecord(sync_event(c, (size_t)k), streams[k]);
+        hipStreamWaitEvent(streams[0], sync_event(c, (size_t)k), 0);
+    }
+    return rc;
 }
 template int trsm_blocked<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, int64_t,
                                   const double*, int64_t);

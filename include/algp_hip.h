@@ -57,7 +57,8 @@ enum {
     ALGP_PROF_SCORE = 6,       /* score + argmax                                    */
     ALGP_PROF_GEMM_OTHER = 7,
     ALGP_PROF_CHOLESKY = 8,    /* wall time of whole train-set factorisations (two overlapped streams) */
-    ALGP_PROF_COUNT = 9
+    ALGP_PROF_TRSM = 9,        /* wall time of whole candidate solves (two overlapped streams)        */
+    ALGP_PROF_COUNT = 10
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
@@ -102,6 +103,11 @@ int algp_factorize(algp_ctx* ctx);
  * only the rest; appending k sites to N costs O((128+k) N^2).  kept_rows (may be NULL) reports how
  * many rows were reused.  The reference refactorises from scratch at every step (agent.py:210).   */
 int algp_factorize_update(algp_ctx* ctx, int64_t* kept_rows);
+/* algp_factorize + algp_solve_candidates as one pipeline: the factorisation runs on a high-priority
+ * stream and the candidate solve follows it column block by column block, so the Cholesky's
+ * latency-bound panel kernels hide under the solve's GEMMs.  Needs algp_set_train and
+ * algp_set_candidates; same results as the two separate calls.                                    */
+int algp_fit_and_solve(algp_ctx* ctx);
 int algp_get_logdet(algp_ctx* ctx, double* logdet);          /* log det S                        */
 int algp_get_entropy(algp_ctx* ctx, double* H);              /* N*CONST + 1/2 log det S (utils.py:188) */
 int algp_get_alpha(algp_ctx* ctx, void* alpha_out);          /* N values                         */

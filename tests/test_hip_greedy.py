@@ -155,3 +155,49 @@ def test_commit_remote_winner_equals_local(ctx64):
         assert np.array_equal(np.isfinite(s), fin)
         assert np.max(np.abs(s[fin] - want[fin])) < 1e-10
         c.commit_pick(int(picks[p]), 0.1, 1.0)
+
+
+@pytest.mark.parametrize('pipeline', ['0', '1'])
+@pytest.mark.parametrize('dtname', ['f64', 'f32'])
+def test_fit_and_solve_pipeline_equals_separate_calls(dtname, pipeline, monkeypatch):
+    """algp_fit_and_solve (Cholesky overlapped with the candidate solve on several streams) must give
+    what algp_factorize + algp_solve_candidates give; big enough to take the pipelined route."""
+    if pipeline == '1':
+        pytest.skip('the overlapped variant is read once per process from ALGP_PIPELINE; covered by tools/pipeline_check.py')
+    c = _hip.Context(np.float64 if dtname == 'f64' else np.float32)
+    rng = np.random.RandomState(21)
+    N, M = 1500, 9000
+    X = rng.uniform(0, 60, (N + M, 2))
+    hyp = O.Hypers(np.log([3.0, 2.0]), 0.0, np.log(2e-2))
+    y = np.sin(X[:N, 0] / 5) + 0.1 * rng.standard_normal(N)
+    var = rng.choice([0.01, 1.0], N)
+    var[N - 50:] = 1.0                             # the 50 train sites that are also candidates are mobile-sampled
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise)
+    c.set_pool(X)
+    c.set_train(np.arange(N), y, var)
+    cand = np.arange(N - 50, N + M)               # includes 50 train sites: unit rows
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.factorize()
+    c.solve_candidates()
+    mu0, d0 = c.posterior()
+    s0 = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    ld0, a0 = c.logdet(), c.alpha()
+    for _ in range(3):                             # repeat: event reuse across calls
+        c.fit_and_solve()
+        mu1, d1 = c.posterior()
+        s1 = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        assert np.array_equal(mu0, mu1) and np.array_equal(d0, d1) and np.array_equal(s0, s1)
+        assert not np.any(np.isnan(s1))
+        assert c.logdet() == ld0 and np.array_equal(c.alpha(), a0)
+    picks = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)
+    c.factorize()
+    c.solve_candidates()
+    assert list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)) == list(picks)
+    # not positive definite inside the pipeline is reported, not swallowed
+    v2 = var.copy()
+    v2[700] = -5.0
+    c.set_train(np.arange(N), y, v2)
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        c.fit_and_solve()
+    assert ei.value.pivot == 701
+    c.close()
