@@ -13,6 +13,7 @@
 #include "common.h"
 #include "mfma.h"
 #include "vecops.h"
+#include <stdlib.h>
 
 namespace algp {
 
@@ -368,7 +369,7 @@ static int chol_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doub
 // CUs with a CU-masked stream: 22.1 ms).  It becomes useful once the diagonal kernel fits beside a
 // GEMM workgroup (<= 96 KB: lower-triangular 16 x 16 block storage).
 template <typename T>
-int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
+static int cholesky_serial(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
     for (int64_t j0 = 0; j0 < npad; j0 += WB) {
         const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
         ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, j0, w));
@@ -385,6 +386,63 @@ int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doubl
         }
     }
     return ALGP_OK;
+}
+
+// One block of look-ahead: while the caller's stream applies block J to the columns right of block
+// J+1 (the bulk of the flops), a helper stream already factors block column J+1.
+template <typename T>
+static int cholesky_lookahead(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
+    const int64_t nblk = (npad + WB - 1) / WB;
+    hipStream_t s1 = c->cur, s2 = (c->cur == c->stream2) ? c->stream3 : c->stream2;
+    struct Restore {
+        algp_ctx* c;
+        hipStream_t s;
+        ~Restore() { c->cur = s; }
+    } restore{c, s1};
+    const size_t E = 40;                                          // sync_event slots of this routine
+    ALGP_HIP(hipEventRecord(sync_event(c, E), s1));
+    ALGP_HIP(hipStreamWaitEvent(s2, sync_event(c, E), 0));
+    c->cur = s2;
+    ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, 0, npad < WB ? npad : WB));
+    ALGP_HIP(hipEventRecord(sync_event(c, E + 1), s2));
+    size_t last = E + 1;
+    for (int64_t J = 0; J < nblk; ++J) {
+        const int64_t j0 = J * WB;
+        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
+        const int64_t r0 = j0 + w;
+        ALGP_HIP(hipStreamWaitEvent(s1, sync_event(c, E + 1 + 2 * (size_t)J), 0));      // panel J factored
+        if (c->record_blk_events) ALGP_HIP(hipEventRecord(sync_event(c, c->blk_event_base + (size_t)J), s1));
+        if (r0 >= npad) break;
+        const int64_t w2 = (npad - r0 < WB) ? npad - r0 : WB;
+        const T* Pb = A + r0 * ld + j0;
+        c->cur = s1;                                              // next block column first
+        ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, npad - r0, w2, w, (T)-1, Pb, ld, Pb, ld, (T)1,
+                                   A + r0 * ld + r0, ld, A + r0 * ld + r0, ld, 0));
+        ALGP_HIP(hipEventRecord(sync_event(c, E + 2 + 2 * (size_t)J), s1));
+        ALGP_HIP(hipStreamWaitEvent(s2, sync_event(c, E + 2 + 2 * (size_t)J), 0));
+        c->cur = s2;
+        ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, r0, w2));
+        ALGP_HIP(hipEventRecord(sync_event(c, E + 3 + 2 * (size_t)J), s2));
+        last = E + 3 + 2 * (size_t)J;
+        const int64_t r1 = r0 + w2;
+        if (r1 < npad) {                                          // the rest, concurrently with that panel
+            c->cur = s1;
+            const T* Pc = A + r1 * ld + j0;
+            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, npad - r1, npad - r1, w, (T)-1, Pc, ld, Pc, ld, (T)1,
+                                       A + r1 * ld + r1, ld, A + r1 * ld + r1, ld, 1));
+        }
+    }
+    ALGP_HIP(hipStreamWaitEvent(s1, sync_event(c, last), 0));
+    c->cur = s1;
+    return ALGP_OK;
+}
+
+template <typename T>
+int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
+    static const int la = getenv("ALGP_CHOL_LOOKAHEAD") ? atoi(getenv("ALGP_CHOL_LOOKAHEAD")) : 0;
+    if (la && npad >= 4 * WB && c->stream2 && c->stream3)
+        return cholesky_lookahead<T>(c, A, npad, ld, invD, logdet_acc, info);
+    return cholesky_serial<T>(c, A, npad, ld, invD, logdet_acc, info);
 }
 template int cholesky_blocked<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*);
 template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*);

@@ -1,0 +1,59 @@
+"""Latency of the GP path at the smaller BASELINE.json configs (parity-test cases, not bench lines):
+C1 20x20 field (n=360), C2 2 000 points fp64, C3 10 000 points fp32 (and fp64 for comparison)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from algp_amd import _hip
+
+
+def run(name, R, C, dt, n_test):
+    rng = np.random.RandomState(1)
+    xx, yy = np.meshgrid(np.arange(C), np.arange(R))
+    X = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)
+    n = len(X)
+    perm = rng.permutation(n)
+    A, T = np.sort(perm[n_test:]), np.sort(perm[:n_test])
+    y = rng.uniform(0, 1, len(A))
+    var = rng.choice([0.01, 1.0], len(A))
+    c = _hip.Context(dt)
+    c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    c.set_pool(X)
+    c.set_train(A, y, var)
+    c.set_candidates(T, prior_includes_noise=False)
+    out = {}
+    for what in ('factorize', 'posterior', 'greedy4'):
+        ts = []
+        for rep in range(6):
+            if what == 'greedy4':
+                c.set_candidates(T, prior_includes_noise=True)
+                c.solve_candidates()
+                c.sync()
+            t0 = time.perf_counter()
+            if what == 'factorize':
+                c.factorize()
+            elif what == 'posterior':
+                c.solve_candidates()
+                c.posterior()
+            else:
+                c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4)
+            c.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out[what + '_ms'] = float(np.median(ts[1:]))
+        if what == 'greedy4':
+            c.set_candidates(T, prior_includes_noise=False)
+    N = len(A)
+    out['N'] = N
+    out['M'] = len(T)
+    out['cholesky_tflops_incl_kernel_build_and_solves'] = N ** 3 / 3.0 / (out['factorize_ms'] * 1e-3) / 1e12
+    c.close()
+    return name, out
+
+
+res = dict([run('C1 20x20 fp64', 20, 20, np.float64, 40), run('C2 50x40 fp64', 50, 40, np.float64, 400),
+            run('C3 100x100 fp32', 100, 100, np.float32, 1000), run('C3 100x100 fp64', 100, 100, np.float64, 1000)])
+print(json.dumps(res, indent=1))
