@@ -125,8 +125,8 @@ def cpu_baseline(w, hyp_vals, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--train', type=int, default=10000)
     ap.add_argument('--cand', type=int, default=100000, help='candidates per GPU')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])

@@ -142,3 +142,42 @@ def test_c4_10000_x_100000_scoring_properties():
     s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
     assert np.max(np.abs(s - ut[3][np.sort(sub) - N])) < 1e-9
     c.close()
+
+
+def test_c5_50000_points_fp64_consistency():
+    """C5 size on one GPU (L = 20 GB): two independent routes to the posterior mean agree
+    (V^T z after the blocked TRSM vs the fused kernel-GEMV with alpha = L^-T z), variances are
+    inside (0, prior], and appending sites through algp_factorize_update reproduces the log-det
+    increment given by the Schur complement of the appended block."""
+    X, f, rng = field(250, 200)
+    n = len(X)
+    assert n == 50000
+    var = rng.choice([0.01, 1.0], n)
+    y = np.maximum(f + rng.standard_normal(n) * np.sqrt(var), 0)
+    Xt = X[rng.permutation(n)[:700]] + 0.41
+    Xnew = X[rng.permutation(n)[:40]] + np.array([0.23, 0.61])
+    pool = np.vstack([X, Xt, Xnew])
+    c = _hip.Context(np.float64)
+    c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+    c.set_pool(pool)
+    c.set_train(np.arange(n), y, var)
+    c.factorize()
+    ld0 = c.logdet()
+    tidx = np.arange(n, n + 700)
+    c.set_candidates(tidx, prior_includes_noise=False)
+    c.solve_candidates()
+    mu, pv = c.posterior()
+    mu2 = c.posterior_mean(tidx)
+    assert np.max(np.abs(mu - mu2)) < 1e-7 * max(1.0, np.max(np.abs(mu)))
+    assert np.all(pv > 0) and np.all(pv <= HYP.outputscale + 1e-12)
+    # append 40 sites: log det grows by log det of their posterior covariance + noise
+    new = np.arange(n + 700, n + 740)
+    c.set_candidates(new, prior_includes_noise=False)
+    c.solve_candidates()
+    cov, _ = c.posterior_cov()
+    want = np.linalg.slogdet(cov + (HYP.noise + 0.01) * np.eye(40))[1]
+    c.set_train(np.r_[np.arange(n), new], np.r_[y, np.zeros(40)], np.r_[var, np.full(40, 0.01)])
+    kept = c.factorize(incremental=True)
+    assert kept == 49920
+    assert c.logdet() - ld0 == pytest.approx(want, rel=1e-8, abs=1e-8)
+    c.close()
