@@ -454,6 +454,25 @@ template <typename T>
 static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                      int64_t ldl, const T* invD, int64_t col_start) {
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
+    if (mpad <= 32 * NB && !c->gate_blk_events) {
+        // A short X (a few test points): the left-looking order below would walk K up to npad inside
+        // one or two workgroups (launch-latency bound).  Right-looking instead: solve one 128-column
+        // block, then update ALL remaining columns with K = 128 -- (npad-k)/128 column tiles in parallel.
+        // It re-reads/re-writes the trailing columns each step, which is negligible for so few rows.
+        if (col_start > 0)      // columns >= col_start still need the contributions of the kept ones
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, npad - col_start, col_start, (T)-1, X, ldx, L + col_start * ldl,
+                                       ldl, (T)1, X + col_start, ldx, X + col_start, ldx, 0));
+        for (int64_t k0 = col_start; k0 < npad; k0 += NB) {
+            T* Xk = X + k0;
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, (T)0,
+                                       nullptr, 0, Xk, ldx, 0));
+            const int64_t nrem = npad - (k0 + NB);
+            if (nrem > 0)
+                ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, nrem, NB, (T)-1, Xk, ldx, L + (k0 + NB) * ldl + k0, ldl, (T)1,
+                                           Xk + NB, ldx, Xk + NB, ldx, 0));
+        }
+        return ALGP_OK;
+    }
     for (int64_t j0 = 0; j0 < npad; j0 += WB) {
         const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
         if (j0 + w <= col_start) continue;
