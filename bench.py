@@ -133,6 +133,8 @@ def main():
     ap.add_argument('--picks', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed/RCCL path even with one rank')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo only for rehearsing several ranks on ONE card (RCCL refuses duplicate devices)')
     ap.add_argument('--cpu-train', type=int, default=8000)
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'traffic.json'))
     args = ap.parse_args()
@@ -146,6 +148,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'ALGP_BENCH_DEVICE' in os.environ:          # rehearsal: several ranks on one card
+        local_rank = int(os.environ['ALGP_BENCH_DEVICE'])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
@@ -157,7 +161,10 @@ def main():
         import torch.distributed as dist
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
 
     from algp_amd import _hip
     from algp_amd.sharded import LocalComm, ShardedGreedy, TorchComm
@@ -204,7 +211,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = {k: ctx.prof_get(k) for k in _hip.PROF}
