@@ -1,0 +1,118 @@
+"""Edge cases and error behaviour of the C-ABI (through ctypes): call order, bad arguments, tiny and
+ragged sizes, empty sets -- the cases the reference handles implicitly (0 x 0 slogdet = 0,
+LinAlgError from inv) or not at all."""
+import numpy as np
+import pytest
+
+from algp_amd import _hip
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+HYP = O.Hypers(np.log([2.0, 2.0]), 0.0, np.log(1e-2))
+
+
+@pytest.fixture()
+def ctx():
+    c = _hip.Context(np.float64)
+    yield c
+    c.close()
+
+
+def test_call_order_errors(ctx):
+    with pytest.raises(ValueError):
+        ctx.set_pool(np.zeros((4, 2)))                       # hypers first
+    ctx.set_hypers(HYP.log_lengthscale, 0.0, HYP.log_noise)
+    with pytest.raises(ValueError):
+        ctx.set_train([0], [1.0])                            # pool first
+    ctx.set_pool(np.random.RandomState(0).uniform(0, 5, (20, 2)))
+    with pytest.raises(ValueError):
+        ctx.factorize()                                      # train set first
+    ctx.set_train(np.arange(10), np.ones(10), np.full(10, 0.01))
+    ctx.set_candidates(np.arange(10, 20), prior_includes_noise=True)
+    with pytest.raises(ValueError):
+        ctx.solve_candidates()                               # factorize first
+    ctx.factorize()
+    with pytest.raises(ValueError):
+        ctx.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)              # solve first
+    ctx.solve_candidates()
+    ctx.set_train(np.arange(9), np.ones(9), np.full(9, 0.01))
+    with pytest.raises(ValueError):
+        ctx.logdet()                                         # the factor is stale after set_train
+
+
+def test_bad_arguments(ctx):
+    ctx.set_hypers(HYP.log_lengthscale, 0.0, HYP.log_noise)
+    ctx.set_pool(np.random.RandomState(0).uniform(0, 5, (20, 2)))
+    with pytest.raises(ValueError):
+        ctx.set_train([0, 25], [1.0, 2.0])                   # index outside the pool
+    with pytest.raises(ValueError):
+        ctx.set_train([3, 3], [1.0, 2.0])                    # duplicate site
+    with pytest.raises(ValueError):
+        ctx.set_candidates([-1])
+    with pytest.raises(ValueError):
+        ctx.set_hypers(np.zeros(9), 0.0, 0.0)                # D > 8
+    ctx.set_train(np.arange(5), np.ones(5))
+    ctx.factorize()
+    ctx.set_candidates(np.arange(5, 20))
+    ctx.solve_candidates()
+    ctx.commit_pick(7, 0.1, 1.0)
+    with pytest.raises(ValueError):
+        ctx.commit_pick(7, 0.1, 1.0)                         # already static
+    with pytest.raises(ValueError):
+        ctx.commit_pick(99, 0.1, 1.0)
+
+
+@pytest.mark.parametrize('N,M', [(0, 7), (1, 1), (2, 129), (127, 1), (128, 128), (129, 127)])
+def test_tiny_and_ragged_sizes(ctx, N, M):
+    rng = np.random.RandomState(N * 7 + M)
+    X = rng.uniform(0, 8, (N + M, 2))
+    y = rng.uniform(0, 1, N)
+    var = rng.choice([0.01, 1.0], N)
+    ctx.set_hypers(HYP.log_lengthscale, 0.0, HYP.log_noise)
+    ctx.set_pool(X)
+    ctx.set_train(np.arange(N), y, var)
+    ctx.factorize()
+    ctx.set_candidates(np.arange(N, N + M), prior_includes_noise=False)
+    ctx.solve_candidates()
+    mu, pv = ctx.posterior()
+    if N == 0:
+        assert ctx.logdet() == 0.0 and ctx.entropy() == 0.0           # 0 x 0 slogdet (agent.py:308 on an empty field)
+        assert np.allclose(pv, HYP.outputscale) and np.allclose(mu, 0.0)
+    else:
+        ref = O.posterior_chol(HYP, X[:N], y, X[N:], var)
+        assert np.max(np.abs(mu - ref['mu'])) < 1e-10 and np.max(np.abs(pv - ref['var'])) < 1e-11
+        assert ctx.logdet() == pytest.approx(ref['logdet'], rel=1e-12, abs=1e-12)
+    cov, mi = ctx.posterior_cov(want_cov=True, want_mi=False)
+    assert cov.shape == (M, M) and np.allclose(np.diag(cov), pv, atol=1e-12)
+
+
+def test_greedy_from_an_empty_field_and_more_picks_than_a_block(ctx):
+    """Empty sampled set (the reference's first batch after reset) and k = 40 picks in one run."""
+    rng = np.random.RandomState(2)
+    X = rng.uniform(0, 15, (150, 2))
+    C = O.kernel_matrix(HYP, X) + HYP.noise * np.eye(150)
+    none = np.zeros(150, bool)
+    want, ut = O.greedy_fast(C, none, none, 0.1, 1.0, 40, 'entropy')
+    ctx.set_hypers(HYP.log_lengthscale, 0.0, HYP.log_noise)
+    ctx.set_pool(X)
+    ctx.set_train(np.zeros(0, np.int64), np.zeros(0))
+    ctx.factorize()
+    ctx.set_candidates(np.arange(150), prior_includes_noise=True)
+    ctx.solve_candidates()
+    picks, u = ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 40, forced_picks=np.array(want), want_utilities=True)
+    fin = np.isfinite(ut)
+    assert np.array_equal(np.isfinite(u), fin) and np.max(np.abs(u[fin] - ut[fin])) < 1e-9
+    assert u[0] == pytest.approx(O.CONST + 0.5 * np.log(HYP.outputscale + HYP.noise + 0.01))
+
+
+def test_two_contexts_are_independent():
+    a, b = _hip.Context(np.float64), _hip.Context(np.float32)
+    x = np.random.RandomState(0).uniform(0, 5, (30, 2))
+    a.set_hypers(HYP.log_lengthscale, 0.0, HYP.log_noise)
+    b.set_hypers(HYP.log_lengthscale + 1.0, 0.5, HYP.log_noise)
+    Ka, Kb = a.kernel_matrix(x), b.kernel_matrix(x)
+    assert Ka.dtype == np.float64 and Kb.dtype == np.float32
+    assert np.allclose(np.diag(Ka), 1.0) and np.allclose(np.diag(Kb), np.exp(0.5), rtol=1e-6)
+    assert a.device_bytes() > 0
+    a.close()
+    b.close()
