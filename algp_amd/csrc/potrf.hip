@@ -451,7 +451,7 @@ template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*
 //   X_J <- X_J - X_{0:J} L_{J,0:J}^T            (one GEMM, n = 512)
 //   inside J, 128 columns at a time: X_k <- (X_k - X_{J0:k} L_{k,J0:k}^T) inv(L_kk)^T
 template <typename T>
-static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
+static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                      int64_t ldl, const T* invD, int64_t col_start) {
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
     if (mpad <= 32 * NB && !c->gate_blk_events) {
@@ -492,6 +492,42 @@ static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
         }
     }
     return ALGP_OK;
+}
+
+// Divide and conquer over the columns [c0, c1) of X (contributions of the columns < c0 are already
+// applied):  solve the left half, subtract its product with the off-diagonal block of L from the right
+// half (ONE GEMM with n = K = half the range), solve the right half.  Same flops as the blocked sweep
+// with squarer GEMMs.  Measured in round 1 (N = 10 000, M = 100 000, fp64): same time (160.9 vs 161.3 ms)
+// but MORE HBM traffic (FETCH x2 + WRITE: 339 GB vs 200 GB per solve) -- the big off-diagonal blocks of L
+// (up to 5120 x 5120) fall out of the 4 MB L2s -- so the blocked sweep stays the default (ALGP_TRSM_MODE=1
+// selects this one).
+template <typename T>
+static int trsm_rec(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t ldl, const T* invD,
+                    int64_t c0, int64_t c1) {
+    if (c1 - c0 == NB) {
+        T* Xk = X + c0;
+        return gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (c0 / NB) * NB * NB, NB, (T)0, nullptr, 0,
+                                 Xk, ldx, 0);
+    }
+    const int64_t half = ((c1 - c0) / NB + 1) / 2 * NB;            // left part: ceil(blocks / 2)
+    const int64_t mid = c0 + half;
+    ALGP_TRY(trsm_rec<T>(c, klass, X, mpad, ldx, L, ldl, invD, c0, mid));
+    ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, c1 - mid, mid - c0, (T)-1, X + c0, ldx, L + mid * ldl + c0, ldl, (T)1,
+                               X + mid, ldx, X + mid, ldx, 0));
+    return trsm_rec<T>(c, klass, X, mpad, ldx, L, ldl, invD, mid, c1);
+}
+
+template <typename T>
+static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
+                     int64_t ldl, const T* invD, int64_t col_start) {
+    static const int mode = getenv("ALGP_TRSM_MODE") ? atoi(getenv("ALGP_TRSM_MODE")) : 0;   // 0 blocked, 1 recursive
+    if (mode == 0 || c->gate_blk_events || mpad <= 32 * NB)
+        return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start);
+    if (col_start >= npad) return ALGP_OK;
+    if (col_start > 0)          // the unsolved columns first receive the contributions of the kept ones
+        ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, npad - col_start, col_start, (T)-1, X, ldx, L + col_start * ldl, ldl,
+                                   (T)1, X + col_start, ldx, X + col_start, ldx, 0));
+    return trsm_rec<T>(c, klass, X, mpad, ldx, L, ldl, invD, col_start, npad);
 }
 
 static hipEvent_t sync_event(algp_ctx* c, size_t i) {
