@@ -85,29 +85,31 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     ALGP_STAMP(0);
     if (tid == 0) bad = 0;
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
     {
-        // block load: 16-byte vectors, 8 loads in flight per thread (a load-per-iteration loop
-        // serialises 64 memory round trips and alone costs >100 us); only block(j) <= block(i) is kept
-        constexpr int VEC = 16 / sizeof(T);
-        typedef T vec_t __attribute__((ext_vector_type(VEC)));
-        constexpr int VPR = 128 / VEC;                  // vectors per row
-        constexpr int NV = 128 * VPR / 256;             // vectors per thread
+        // block load over (row, 16-column block) pairs of the lower block triangle: 16-byte global loads,
+        // all of a thread's loads in flight before the first LDS store (a load-per-iteration loop serialises
+        // 64 memory round trips and alone costs >100 us)
+        vec_t tmp[4][16 / VEC];
 #pragma unroll
-        for (int b0 = 0; b0 < NV; b0 += 8) {
-            vec_t tmp[8];
+        for (int u = 0; u < 4; ++u) {
+            // loaded unconditionally (the whole 128 x 128 block is addressable): a load under a runtime
+            // condition makes hipcc branch around it and wait for every load separately
+            const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = tid + 256 * (b0 + u);
-                tmp[u] = *reinterpret_cast<const vec_t*>(A + (int64_t)(v / VPR) * lda + (v % VPR) * VEC);
-            }
+            for (int v = 0; v < 16 / VEC; ++v)
+                tmp[u][v] = *reinterpret_cast<const vec_t*>(A + (int64_t)i * lda + 16 * J + v * VEC);
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = tid + 256 * (b0 + u);
-                const int i = v / VPR, j = (v % VPR) * VEC;
-                if ((j >> 4) <= (i >> 4)) {
+        for (int u = 0; u < 4; ++u) {
+            const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7;
+            if (J <= (i >> 4)) {
+                T* dst = S + LB(i, 16 * J);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) S[LB(i, j + e)] = tmp[u][e];
-                }
+                for (int v = 0; v < 16 / VEC; ++v)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) dst[v * VEC + e] = tmp[u][v][e];
             }
         }
     }
@@ -148,11 +150,12 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
             __syncthreads();
             if (k0 == 0) ALGP_STAMP(3);
             if (active) {
-                const int i = k0 + rowid;
+                // branch-free: entries above the diagonal of the 16 x 16 block receive scratch values
+                // (that part of the block is free storage until the inverse phase overwrites it)
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    if (i > k0 + c) S[myrow + c] = a[c] * dinv[k0 + c];
-                    else if (i == k0 + c) S[myrow + c] = dd[i] * dinv[i];          // sqrt(d) = d / sqrt(d)
+                    const T dv = dinv[k0 + c];
+                    S[myrow + c] = (rowid == c) ? dd[k0 + c] * dv : a[c] * dv;      // sqrt(d) = d / sqrt(d)
                 }
             }
             __syncthreads();
@@ -162,22 +165,45 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
             if (r > 0) {
                 const int K0 = k0 >> 4, K1 = k1 >> 4;
                 const int nb16 = r >> 4, ntile16 = nb16 * (nb16 + 1) / 2;
-                for (int t = wave; t < ntile16; t += 4) {
-                    int ti = 0;
+                // two tiles per trip: their loads and MFMA chains are independent and overlap
+                for (int t = wave; t < ntile16; t += 8) {
+                    const int t2 = t + 4;
+                    const bool two = t2 < ntile16;
+                    int ti = 0, tj = 0;
                     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
                     const int tk = t - ti * (ti + 1) / 2;
-                    const int bi = K1 + ti, bk = K1 + tk;
+                    const int tt = two ? t2 : t;
+                    while ((tj + 1) * (tj + 2) / 2 <= tt) ++tj;
+                    const int tl = tt - tj * (tj + 1) / 2;
+                    const int bi = K1 + ti, bk = K1 + tk, ci = K1 + tj, ck = K1 + tl;
                     const T* Pa = S + (bi * (bi + 1) / 2 + K0) * DBS;
                     const T* Pb = S + (bk * (bk + 1) / 2 + K0) * DBS;
+                    const T* Qa = S + (ci * (ci + 1) / 2 + K0) * DBS;
+                    const T* Qb = S + (ck * (ck + 1) / 2 + K0) * DBS;
                     T* Cb = S + (bi * (bi + 1) / 2 + bk) * DBS;
-                    typename F::acc_t acc;
+                    T* Cq = S + (ci * (ci + 1) / 2 + ck) * DBS;
+                    T pa[4], pb[4], qa[4], qb[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = (T)0;
+                    for (int st = 0; st < 4; ++st) {
+                        pa[st] = Pa[li * 17 + 4 * st + lg];
+                        pb[st] = Pb[li * 17 + 4 * st + lg];
+                        qa[st] = Qa[li * 17 + 4 * st + lg];
+                        qb[st] = Qb[li * 17 + 4 * st + lg];
+                    }
+                    typename F::acc_t acc, acq;
 #pragma unroll
-                    for (int st = 0; st < 4; ++st)
-                        acc = F::mfma(Pa[li * 17 + 4 * st + lg], Pb[li * 17 + 4 * st + lg], acc);
+                    for (int q = 0; q < 4; ++q) { acc[q] = (T)0; acq[q] = (T)0; }
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        acc = F::mfma(pa[st], pb[st], acc);
+                        acq = F::mfma(qa[st], qb[st], acq);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) Cb[F::row_of(lane, q) * 17 + li] -= acc[q];
+                    if (two) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Cq[F::row_of(lane, q) * 17 + li] -= acq[q];
+                    }
                 }
                 __syncthreads();
                 if (k0 == 0) ALGP_STAMP(5);
@@ -194,9 +220,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
             atomicAdd(logdet_acc, red[0] + red[1]);
             if (bad) atomicCAS(info, 0, (int)(block_row0 + bad));
         }
-        for (int e = tid; e < 128 * 128; e += 256) {
-            const int i = e >> 7, j = e & 127;
-            if (j <= i) A[(int64_t)i * lda + j] = S[LB(i, j)];
+        // write L back, whole 16-element block rows (the strict upper part of the diagonal blocks carries
+        // scratch values: nothing reads it -- see DESIGN.md "data layout")
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7;
+            if (J <= (i >> 4)) {
+                const T* src = S + LB(i, 16 * J);
+#pragma unroll
+                for (int v = 0; v < 16 / VEC; ++v) {
+                    vec_t o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e] = src[v * VEC + e];
+                    *reinterpret_cast<vec_t*>(A + (int64_t)i * lda + 16 * J + v * VEC) = o;
+                }
+            }
         }
     } else {
         if (tid < 128) dinv[tid] = (T)1 / S[LB(tid, tid)];
@@ -209,20 +247,16 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
     if (tid < 128) {
         const int I = tid >> 4, c = tid & 15, base = I * 16;
         T* Db = S + (I * (I + 1) / 2 + I) * DBS;
+        // x[k] = 0 for k < c, so the sums run over all k < i with unconditional (broadcast) LDS loads
         T x[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = (T)0;
-#pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (i == c) x[i] = dinv[base + c];
-            if (i > c) {
-                T sum = (T)0;
+            T sum = (T)0;
 #pragma unroll
-                for (int k = 0; k < i; ++k)
-                    if (k >= c) sum += Db[i * 17 + k] * x[k];
-                x[i] = -sum * dinv[base + i];
-            }
+            for (int k = 0; k < i; ++k) sum += Db[i * 17 + k] * x[k];
+            x[i] = (i == c) ? dinv[base + c] : ((i > c) ? -sum * dinv[base + i] : (T)0);
         }
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // all reads of the block have landed before its upper part is written
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             if (i > c) Db[c * 17 + i] = x[i];
@@ -289,15 +323,31 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* i
         __syncthreads();
         ALGP_STAMP(9 + I);
     }
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        T v = (T)0;
-        if ((j >> 4) < (i >> 4)) v = S[LB(i, j)];
-        else if ((j >> 4) == (i >> 4)) {
-            if (j < i) v = S[LB(i, i) - (i & 15) * 17 - (i & 15) + (j & 15) * 17 + (i & 15)];   // upper, transposed: (j, i)
-            else if (j == i) v = dinv[i];
+    // inverse out, 16 elements of a row at a time: left of the diagonal block X_IJ rows, inside it the
+    // transposed upper storage with dinv on the diagonal, zeros to the right
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7, I = i >> 4, r = i & 15;
+        T row[16];
+        if (J < I) {
+            const T* src = S + LB(i, 16 * J);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) row[e] = src[e];
+        } else if (J == I) {
+            const T* Db = S + (I * (I + 1) / 2 + I) * DBS;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) row[e] = (e < r) ? Db[e * 17 + r] : (e == r ? dinv[i] : (T)0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) row[e] = (T)0;
         }
-        inv_out[i * 128 + j] = v;
+#pragma unroll
+        for (int v = 0; v < 16 / VEC; ++v) {
+            vec_t o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = row[v * VEC + e];
+            *reinterpret_cast<vec_t*>(inv_out + i * 128 + 16 * J + v * VEC) = o;
+        }
     }
     ALGP_STAMP(17);
 }
