@@ -8,6 +8,12 @@ import os
 
 import numpy as np
 
+# The library overlaps independent row chunks of the candidate solve on several HIP streams; ROCm maps all
+# streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and streams that share a queue
+# serialise.  With RCCL (or torch) streams in the same process 4 is not enough (measured: 161 -> 183 ms).
+# Only effective if set before the HIP runtime initialises, hence at import time.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libalgp_hip.so')
 

@@ -384,8 +384,7 @@ struct Impl {
         c->logdet = ld_total;
         ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
         ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z)));
-        ALGP_HIP(hipMemcpyAsync(c->alpha.p, c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
-        ALGP_TRY(trsv_backward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->alpha)));
+        c->alpha_valid = false;                   // alpha = L^-T z: on first use (need_alpha)
         std::vector<T> zh(Npad);
         ALGP_HIP(hipMemcpyAsync(zh.data(), c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToHost, c->stream));
         ALGP_TRY(sync(c));
@@ -399,6 +398,14 @@ struct Impl {
         c->fact_var = c->train_var_host;
         c->fact_hyp_stamp = c->hyp_stamp;
         c->kept_rows_last = keep;
+        return ALGP_OK;
+    }
+
+    static int need_alpha(algp_ctx* c) {
+        if (c->alpha_valid) return ALGP_OK;
+        ALGP_HIP(hipMemcpyAsync(c->alpha.p, c->z.p, sizeof(T) * c->Npad, hipMemcpyDeviceToDevice, c->stream));
+        ALGP_TRY(trsv_backward<T>(c, p(c->L), c->Npad, c->Lld, p(c->invD), p(c->alpha)));
+        c->alpha_valid = true;
         return ALGP_OK;
     }
 
@@ -670,6 +677,7 @@ struct Impl {
         for (int64_t i = 0; i < N; ++i) q += (double)zh[i] * (double)zh[i];
         c->yalpha = q;
         c->factored = true;
+        c->alpha_valid = true;
         c->train_dirty = false;
         c->Nfact = N;
         c->fact_idx = c->train_idx;
@@ -732,6 +740,7 @@ struct Impl {
         ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * M));
         ALGP_TRY(ensure(c, c->auxD, sizeof(T) * M));
         ALGP_HIP(hipMemcpyAsync(c->auxIdx.p, idx, sizeof(int64_t) * M, hipMemcpyHostToDevice, c->stream));
+        ALGP_TRY(need_alpha(c));
         ALGP_TRY(kgemv_launch<T>(c, M, (const int64_t*)c->auxIdx.p, (const T*)c->Xs.p, c->hyp.DP, c->N,
                                  (const int64_t*)c->Aidx.p, (const T*)c->alpha.p, c->hyp.kernel, (T)c->hyp.outputscale,
                                  (T)c->ybar, p(c->auxD)));
@@ -1078,6 +1087,7 @@ struct Impl {
         if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "get_mll_grad needs a coordinate pool");
         const int64_t N = c->N, Npad = c->Npad;
         const int D = c->hyp.D, DP = c->hyp.DP;
+        ALGP_TRY(need_alpha(c));
         ALGP_TRY(ensure(c, c->auxW, sizeof(T) * Npad * Npad));
         ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Npad * Npad));
         // X = I L^-T = L^-T ;  S^-1 = X X^T (lower tiles)
@@ -1100,6 +1110,7 @@ struct Impl {
 
     static int get_alpha(algp_ctx* c, void* out) {
         if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_alpha: call algp_factorize first");
+        ALGP_TRY(need_alpha(c));
         ALGP_HIP(hipMemcpyAsync(out, c->alpha.p, sizeof(T) * c->N, hipMemcpyDeviceToHost, c->stream));
         return sync(c);
     }
@@ -1144,6 +1155,9 @@ int algp_device_count(void) {
 int algp_create(int device_id, int dtype, algp_ctx** out) {
     if (!out || (dtype != ALGP_F32 && dtype != ALGP_F64)) return ALGP_ERR_BAD_ARG;
     *out = nullptr;
+    // more hardware queues than the default 4 so the helper streams do not share one with RCCL / torch
+    // streams of the same process (no effect if the HIP runtime is already initialised)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ALGP_ERR_NO_DEVICE; }
     if (device_id < 0 || device_id >= n) return ALGP_ERR_BAD_ARG;

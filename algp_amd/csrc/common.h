@@ -86,6 +86,7 @@ struct algp_ctx {
     algp::DevBuf Aidx, yA, varA, y0, L, invD, z, alpha, scal;   // scal: device doubles (logdet, info...)
     double ybar = 0, logdet = 0, yalpha = 0;
     bool factored = false;
+    bool alpha_valid = false;            // alpha = L^-T z is computed on first use (scoring does not need it)
 
     // candidates
     int64_t M = 0, Mpad = 0, ldv = 0;

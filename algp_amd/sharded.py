@@ -56,12 +56,41 @@ class TorchComm(object):
         return self._send, self._recv
 
     def all_gather(self, local, max_len):
+        """Returns the gathered (world, max_len) score matrix: a torch tensor on the GPU with the
+        nccl backend (it never visits the host), a NumPy array otherwise."""
         send, recv = self.buffers(max_len)
         if local is not None:                       # host scores (gloo)
             send.fill_(float('-inf'))
             send[:len(local)] = self.torch.from_numpy(np.ascontiguousarray(local))
         self.dist.all_gather_into_tensor(recv.view(-1), send)
-        return recv.cpu().numpy() if self.device_buffers else recv.numpy()
+        return recv if self.device_buffers else recv.numpy()
+
+    def first_max(self, g, parts):
+        """(global position, value) of the first maximum in rank order (np.argmax semantics,
+        agent.py:349) of the gathered scores; on the GPU for device buffers (two scalars come back)."""
+        if not self.device_buffers:
+            return _first_max_numpy(g, parts)
+        t = self.torch
+        flat = g.view(-1)
+        m = flat.max()
+        pos = int(t.nonzero(flat == m)[0].item()) if not bool(t.isnan(m)) else 0
+        r, j = divmod(pos, g.shape[1])              # padding is -inf and only wins when everything is -inf
+        lo, hi = parts[r]
+        if j >= hi - lo:                            # every score is -inf: fall back to the first candidate
+            r = next(k for k, (l, h) in enumerate(parts) if h > l)
+            lo, j = parts[r][0], 0
+        return lo + j, float(m.item())
+
+
+def _first_max_numpy(g, parts):
+    best_v, best_pos = -np.inf, -1
+    for r, (lo, hi) in enumerate(parts):                # first maximum in global order
+        if hi > lo:
+            seg = np.asarray(g[r, :hi - lo])
+            j = int(np.argmax(seg))
+            if best_pos < 0 or seg[j] > best_v:
+                best_v, best_pos = float(seg[j]), lo + j
+    return best_pos, best_v
 
 
 class ShardedGreedy(object):
@@ -94,13 +123,10 @@ class ShardedGreedy(object):
     def step(self, criterion, static_std, mobile_std):
         """One pick: returns (pool index of the winner, its utility)."""
         g = self._gather_scores(criterion, static_std, mobile_std)
-        best_v, best_pos = -np.inf, -1
-        for r, (lo, hi) in enumerate(self.parts):          # first maximum in global order
-            if hi > lo:
-                seg = g[r, :hi - lo]
-                j = int(np.argmax(seg))
-                if best_pos < 0 or seg[j] > best_v:
-                    best_v, best_pos = float(seg[j]), lo + j
+        if hasattr(self.comm, 'first_max') and not isinstance(g, np.ndarray):
+            best_pos, best_v = self.comm.first_max(g, self.parts)
+        else:
+            best_pos, best_v = _first_max_numpy(g, self.parts)
         winner = int(self.all_idx[best_pos])
         self.b.commit_pick(winner, static_std, mobile_std)
         return winner, best_v

@@ -22,6 +22,11 @@ import time
 
 import numpy as np
 
+# The candidate solve overlaps independent row chunks on 3 HIP streams.  ROCm multiplexes all streams of
+# a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues; once RCCL's streams exist the chunk streams
+# share a queue and serialise (TRSM 161 -> 183 ms).  Must be set before the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
