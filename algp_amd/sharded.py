@@ -112,7 +112,7 @@ class ShardedGreedy(object):
             raise ValueError('backend holds %d candidates, this rank owns %d' % (backend.M, self.hi - self.lo))
 
     def _gather_scores(self, criterion, static_std, mobile_std):
-        if self.comm.world_size == 1:
+        if isinstance(self.comm, LocalComm):
             return self.b.scores(criterion, static_std, mobile_std)[None, :]
         if self.comm.device_buffers:
             send, _ = self.comm.buffers(self.max_len)
