@@ -523,8 +523,9 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
         }
         return ALGP_OK;
     }
-    for (int64_t j0 = 0; j0 < npad; j0 += WB) {
-        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
+    static const int64_t TWB = getenv("ALGP_TRSM_WB") ? atoll(getenv("ALGP_TRSM_WB")) : WB;   // outer block width
+    for (int64_t j0 = 0; j0 < npad; j0 += TWB) {
+        const int64_t w = (npad - j0 < TWB) ? npad - j0 : TWB;
         if (j0 + w <= col_start) continue;
         if (c->gate_blk_events) ALGP_HIP(hipStreamWaitEvent(c->cur, sync_event(c, c->blk_event_base + (size_t)(j0 / WB)), 0));
         const int64_t cs = j0 > col_start ? j0 : col_start;         // first column of this block to solve
