@@ -12,11 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from algp_amd import _hip
 
 rng = np.random.RandomState(1)
-N0, M, steps = 10000, 100000, 6
-xx, yy = np.meshgrid(np.arange(100), np.arange(100))
+R0, C0 = (int(v) for v in os.environ.get('LOOP_GRID', '100x100').split('x'))
+N0, M, steps = R0 * C0, 100000, int(os.environ.get('LOOP_STEPS', '6'))
+xx, yy = np.meshgrid(np.arange(C0), np.arange(R0))
 Xa = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)
 ii, jj = np.meshgrid(np.arange(400), np.arange(250), indexing='ij')
-Xc = np.vstack([(ii.ravel() + 0.37) * 0.25, (jj.ravel() + 0.41) * 0.4]).T[:M]
+Xc = np.vstack([(ii.ravel() + 0.37) * (R0 / 400.0), (jj.ravel() + 0.41) * (C0 / 250.0)]).T[:M]
 Xc = Xc + 0.03 * rng.standard_normal(Xc.shape)        # generic positions: no exact lattice ties
 pool = np.vstack([Xa, Xc])
 y0 = rng.uniform(0, 1, N0)
