@@ -1092,9 +1092,8 @@ struct Impl {
         ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Npad * Npad));
         // X = I L^-T = L^-T ;  S^-1 = X X^T (lower tiles)
         ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), Npad, Npad));
-        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), Npad, c->Lld, p(c->invD)));
-        ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, Npad, Npad, Npad, (T)1, p(c->auxW), Npad, p(c->auxW), Npad,
-                                   (T)0, nullptr, 0, p(c->auxA), Npad, 1));
+        ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), c->Lld, p(c->invD)));
+        ALGP_TRY(syrk_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->auxA), Npad));
         double* sc = (double*)c->scal.p + 16;             // slots 16..27: os, trace, ls[0..8)
         ALGP_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 12, c->stream));
         ALGP_TRY(mll_grad_launch<T>(c, p(c->auxA), Npad, N, (const T*)c->Xs.p, DP, (const int64_t*)c->Aidx.p,

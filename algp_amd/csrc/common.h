@@ -180,6 +180,7 @@ int kmat_xy_launch(algp_ctx* c, const T* xs1, int64_t n1, const T* xs2, int64_t 
 template <typename T>
 int scale_coords_launch(algp_ctx* c, const T* x, int64_t n, T* xs);
 
+// D = alpha A B^T + beta C.  lower_only: square output, only the tiles on/below the diagonal.
 template <typename T>
 int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
@@ -199,6 +200,12 @@ int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doubl
 template <typename T>
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                  int64_t ldl, const T* invD, int64_t col_start = 0);
+// X (npad x npad, holding the identity) <- L^-T (upper triangular; zero parts are never touched)
+template <typename T>
+int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T* L, int64_t ldl, const T* invD);
+// C (lower tiles, npad x npad) <- X X^T for that upper-triangular X
+template <typename T>
+int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T* C, int64_t ldc);
 // b <- L^-1 b (forward) and b <- L^-T b (backward) for one vector of length npad
 template <typename T>
 int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b);

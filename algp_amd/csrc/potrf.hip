@@ -545,6 +545,51 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
     return ALGP_OK;
 }
 
+// X (npad x npad, holding the identity) <- L^-T, which is UPPER triangular: row r is zero left of
+// column r, so only the rows above a column block ever take part: N^3/6 multiply-adds instead of the
+// N^3/2 of a dense right-hand side.  RIGHT-looking over 512-wide column blocks -- a left-looking sweep
+// has at most (rows above)/128 x 4 tiles per launch, each walking the whole K (measured: 14.5 ms at
+// N = 9000, 204 workgroups on the last block); pushing each solved block into all trailing columns
+// gives (j0+w)/128 x (npad-j0-w)/128 tiles with K = 512, the shape of the Cholesky's trailing update.
+template <typename T>
+int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T* L, int64_t ldl, const T* invD) {
+    for (int64_t j0 = 0; j0 < npad; j0 += WB) {
+        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB, j1 = j0 + w;
+        for (int64_t k0 = j0; k0 < j1; k0 += NB) {
+            T* Xk = X + k0;
+            const int64_t rows = k0 + NB;                         // rows below are zero in this column block
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, rows, NB, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, (T)0,
+                                       nullptr, 0, Xk, ldx, 0));
+            if (k0 + NB < j1)
+                ALGP_TRY(gemm_nt_launch<T>(c, klass, rows, j1 - (k0 + NB), NB, (T)-1, Xk, ldx, L + (k0 + NB) * ldl + k0,
+                                           ldl, (T)1, Xk + NB, ldx, Xk + NB, ldx, 0));
+        }
+        if (j1 < npad)
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, j1, npad - j1, w, (T)-1, X + j0, ldx, L + j1 * ldl + j0, ldl, (T)1,
+                                       X + j1, ldx, X + j1, ldx, 0));
+    }
+    return ALGP_OK;
+}
+
+// C (lower tiles) <- X X^T for the upper-triangular X above, as a sum over 512-wide column panels of X:
+// panel kp is zero below row kp + 512, so it only touches the leading (kp+512)^2 corner.  Descending kp,
+// so that the first (full-size) launch initialises every tile.  K = 512 panels stay L2/MALL-resident;
+// one GEMM with K = N streams X from HBM once per tile row (measured 28 TFLOP/s at N = 9000).
+template <typename T>
+int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T* C, int64_t ldc) {
+    const int64_t last = (npad - 1) / WB * WB;
+    for (int64_t kp = last; kp >= 0; kp -= WB) {
+        const int64_t w = (npad - kp < WB) ? npad - kp : WB, m = kp + w;
+        ALGP_TRY(gemm_nt_launch<T>(c, klass, m, m, w, (T)1, X + kp, ldx, X + kp, ldx, kp == last ? (T)0 : (T)1, C, ldc, C,
+                                   ldc, 1));
+    }
+    return ALGP_OK;
+}
+template int syrk_upper<double>(algp_ctx*, int, const double*, int64_t, int64_t, double*, int64_t);
+template int syrk_upper<float>(algp_ctx*, int, const float*, int64_t, int64_t, float*, int64_t);
+template int trinv_upper<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, const double*);
+template int trinv_upper<float>(algp_ctx*, int, float*, int64_t, int64_t, const float*, int64_t, const float*);
+
 // Divide and conquer over the columns [c0, c1) of X (contributions of the columns < c0 are already
 // applied):  solve the left half, subtract its product with the off-diagonal block of L from the right
 // half (ONE GEMM with n = K = half the range), solve the right half.  Same flops as the blocked sweep

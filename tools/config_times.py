@@ -46,6 +46,14 @@ def run(name, R, C, dt, n_test):
         out[what + '_ms'] = float(np.median(ts[1:]))
         if what == 'greedy4':
             c.set_candidates(T, prior_includes_noise=False)
+    ts = []
+    for rep in range(5):                       # one hyper-parameter fit iteration (f2): factor + MLL + gradient
+        t0 = time.perf_counter()
+        c.factorize()
+        c.mll()
+        c.mll_grad()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    out['fit_iteration_ms'] = float(np.median(ts[1:]))
     N = len(A)
     out['N'] = N
     out['M'] = len(T)
