@@ -466,9 +466,12 @@ struct Impl {
             if (keep == 0) became_unit.clear();
         }
         c->solved = false;
-        if (!c->Vt.p || c->ldv_cap < ldv || (keep == 0 && c->ldv_cap != ldv) || c->Vt.cap < sizeof(T) * Mpad * c->ldv_cap) {
-            // (re)allocate; keep the valid columns when growing
-            const int64_t newcap = keep > 0 ? round_up(ldv + ldv / 8, NB) : ldv;
+        if (!c->Vt.p || c->ldv_cap < ldv || (keep == 0 && !incremental && c->ldv_cap != ldv) ||
+            c->Vt.cap < sizeof(T) * Mpad * c->ldv_cap) {
+            // (re)allocate; keep the valid columns when growing.  A caller that asks for reuse gets 12.5 %
+            // headroom in the row stride from the start, so that a growing train set does not force a
+            // re-layout (a 2-D copy of all of V^T) the first time it crosses a 128 boundary.
+            const int64_t newcap = incremental ? round_up(ldv + ldv / 8, NB) : ldv;
             DevBuf nv;
             ALGP_TRY(ensure(c, nv, sizeof(T) * Mpad * newcap));
             if (keep > 0) {
@@ -522,6 +525,7 @@ struct Impl {
         ALGP_TRY(sync(c));
         c->ncols = Npad;
         c->picks.clear();
+        c->lazy_stale = false;
         c->solved = true;
         c->vt_fact_idx = c->fact_idx;
         c->vt_fact_var = c->fact_var;
@@ -686,6 +690,7 @@ struct Impl {
         c->kept_rows_last = 0;
         c->ncols = Npad;
         c->picks.clear();
+        c->lazy_stale = false;
         c->solved = true;
         c->vt_fact_idx = c->fact_idx;
         c->vt_fact_var = c->fact_var;
@@ -700,6 +705,7 @@ struct Impl {
 
     static int get_posterior(algp_ctx* c, void* mu, void* var) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "get_posterior: call algp_solve_candidates first");
+        ALGP_TRY(flush_lazy(c));
         if (mu) ALGP_HIP(hipMemcpyAsync(mu, c->mu.p, sizeof(T) * c->M, hipMemcpyDeviceToHost, c->stream));
         if (var) ALGP_HIP(hipMemcpyAsync(var, c->dstat.p, sizeof(T) * c->M, hipMemcpyDeviceToHost, c->stream));
         return sync(c);
@@ -775,12 +781,12 @@ struct Impl {
         return ALGP_OK;
     }
 
-    // diag(S^-1) = row sums of squares of L^-T (= I * L^-T through the blocked TRSM)
+    // diag(S^-1) = row sums of squares of L^-T (the triangular inverse on the MFMA GEMM)
     static int inverse_diag_resident(algp_ctx* c, int64_t m, int64_t mpad, void* diag_out) {
         ALGP_TRY(ensure(c, c->auxW, sizeof(T) * mpad * mpad));
         ALGP_TRY(ensure(c, c->auxD, sizeof(T) * mpad));
         ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), mpad, mpad));
-        ALGP_TRY(trsm_blocked<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), mpad, mpad, p(c->auxA), mpad, mpad, p(c->auxInv)));
+        ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), mpad, mpad, p(c->auxA), mpad, p(c->auxInv)));
         ALGP_TRY(rows_reduce_launch<T>(c, p(c->auxW), m, mpad, mpad, (const T*)nullptr, p(c->auxD), (T*)nullptr));
         ALGP_HIP(hipMemcpyAsync(diag_out, c->auxD.p, sizeof(T) * m, hipMemcpyDeviceToHost, c->stream));
         return sync(c);
@@ -915,6 +921,7 @@ struct Impl {
     static int scores(algp_ctx* c, int criterion, double static_std, double mobile_std, void* out, int out_is_device) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "scores: call algp_solve_candidates first");
         if (!c->prior_noise) return fail(c, ALGP_ERR_STATE, "scores: candidates were set with predictive semantics");
+        ALGP_TRY(flush_lazy(c));
         const double ss = static_std * static_std, sm = mobile_std * mobile_std;
         const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
         const double* extra_dev = nullptr;
@@ -1018,6 +1025,7 @@ struct Impl {
 
     static int commit_pick(algp_ctx* c, int64_t pool_idx, double static_std, double mobile_std) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "commit_pick: call algp_solve_candidates first");
+        ALGP_TRY(flush_lazy(c));
         if (pool_idx < 0 || pool_idx >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: index outside the pool");
         if ((int64_t)c->picks.size() >= MAX_APPEND) return fail(c, ALGP_ERR_STATE, "commit_pick: append capacity exhausted; re-factorize");
         for (auto& pk : c->picks)
@@ -1066,8 +1074,97 @@ struct Impl {
         return ALGP_OK;
     }
 
+    // ---- lazy greedy (entropy criterion, picks only): see lazy_refresh_kernel in vecops.hip ----
+    static int lazy_launch(algp_ctx* c, int mode, int64_t pos, double ss, double delta) {
+        return lazy_refresh_launch<T>(c, c->M, mode, pos, (const LazyPick*)c->lazypicks.p, (int)c->picks.size(),
+                                      (const int*)c->ckind.p, (const int64_t*)c->Cidx.p, (const T*)c->Xs.p,
+                                      c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, c->hyp.DP, c->hyp.kernel,
+                                      (T)c->hyp.outputscale, (T)c->hyp.noise, p(c->prevrows), c->ldv, p(c->Vt),
+                                      p(c->dstat), (int*)c->fresh.p, (const unsigned char*)c->alive.p,
+                                      (double*)c->scores.p, ss, delta);
+    }
+    // bring every row of V^T / dstat up to date with the committed picks (stream-ordered, no host sync)
+    static int flush_lazy(algp_ctx* c) {
+        if (!c->lazy_stale) return ALGP_OK;
+        ALGP_TRY(lazy_launch(c, 2, 0, c->lazy_ss, c->lazy_delta));
+        c->lazy_stale = false;
+        return ALGP_OK;
+    }
+
+    // commit the local candidate `local` without touching the other rows (they catch up on demand)
+    static int commit_lazy(algp_ctx* c, int64_t local, double ss, double delta) {
+        const int64_t pool_idx = c->cand_idx[local];
+        if ((int64_t)c->picks.size() >= MAX_APPEND) return fail(c, ALGP_ERR_STATE, "commit_pick: append capacity exhausted; re-factorize");
+        for (auto& pk : c->picks)
+            if (pk.pool_idx == pool_idx) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: site already static-sampled");
+        const int in_train = c->pos_in_train[pool_idx] >= 0 ? 1 : 0;
+        const int64_t ldv = c->ldv, ncols = c->ncols;
+        const size_t q = c->picks.size();
+        T* prev = p(c->prevrows) + (int64_t)q * ldv;
+        ALGP_HIP(hipMemsetAsync(prev, 0, sizeof(T) * ldv, c->stream));
+        ALGP_HIP(hipMemcpyAsync(prev, p(c->Vt) + local * ldv, sizeof(T) * ncols, hipMemcpyDeviceToDevice, c->stream));
+        T dch;
+        ALGP_HIP(hipMemcpyAsync(&dch, p(c->dstat) + local, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        const double dc = (double)dch;
+        const double scale = in_train ? sqrt(-(delta / (1.0 + delta * dc))) : 1.0 / sqrt(dc + ss);
+        if (!(scale == scale) || isinf(scale))
+            return fail(c, ALGP_ERR_NOT_PD, "commit_pick: posterior variance of the pick is not positive");
+        LazyPick lp;
+        lp.pool_idx = pool_idx;
+        lp.ncols = ncols;
+        lp.scale = scale;
+        lp.in_train = in_train;
+        static const double neg_inf = -INFINITY;
+        ALGP_HIP(hipMemcpyAsync((LazyPick*)c->lazypicks.p + q, &lp, sizeof(lp), hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemsetAsync((unsigned char*)c->alive.p + local, 0, 1, c->stream));
+        ALGP_HIP(hipMemcpyAsync((double*)c->scores.p + local, &neg_inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        ALGP_TRY(sync(c));
+        PickRec pr;
+        pr.pool_idx = pool_idx;
+        pr.in_train = in_train;
+        pr.scale = scale;
+        c->picks.push_back(pr);
+        c->ncols = ncols + 1;
+        c->lazy_stale = true;
+        return ALGP_OK;
+    }
+
+    static int greedy_lazy(algp_ctx* c, double static_std, double mobile_std, int k, int64_t* picks_out) {
+        const double ss = static_std * static_std, sm = mobile_std * mobile_std;
+        const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
+        // full utilities once (flushes rows left stale by an earlier call); from here on c->scores holds,
+        // per row, the utility as of the picks applied to that row -- an upper bound of the current one
+        ALGP_TRY(scores(c, ALGP_CRIT_ENTROPY, static_std, mobile_std, nullptr, 0));
+        ALGP_TRY(ensure(c, c->fresh, sizeof(int) * c->Mpad));
+        ALGP_TRY(ensure(c, c->lazypicks, sizeof(LazyPick) * MAX_APPEND));
+        ALGP_HIP(hipMemsetD32Async((hipDeviceptr_t)c->fresh.p, (int)c->picks.size(), (size_t)c->Mpad, c->stream));
+        c->lazy_ss = ss;
+        c->lazy_delta = delta;
+        for (int pck = 0; pck < k; ++pck) {
+            int64_t pos;
+            for (;;) {
+                ALGP_TRY(argmax(c, &pos, nullptr, nullptr));
+                if (pos < 0) return fail(c, ALGP_ERR_BAD_ARG, "greedy: every utility is NaN");
+                if (!c->lazy_stale) break;                            // nothing committed since the full scoring
+                int f;
+                ALGP_HIP(hipMemcpyAsync(&f, (const int*)c->fresh.p + pos, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                ALGP_TRY(sync(c));
+                if (f >= (int)c->picks.size()) break;                 // the maximum is an up-to-date row: it wins
+                ALGP_TRY(lazy_launch(c, 0, pos, ss, delta));          // the best bound becomes a true value ...
+                ALGP_TRY(lazy_launch(c, 1, pos, ss, delta));          // ... and every bound reaching it is resolved
+            }
+            if (picks_out) picks_out[pck] = c->cand_idx[pos];
+            ALGP_TRY(commit_lazy(c, pos, ss, delta));
+        }
+        return ALGP_OK;
+    }
+
     static int greedy(algp_ctx* c, int criterion, double static_std, double mobile_std, int k, const int64_t* forced,
                       int64_t* picks_out, double* ut_out) {
+        static const bool lazy_on = !(getenv("ALGP_LAZY_GREEDY") && atoi(getenv("ALGP_LAZY_GREEDY")) == 0);
+        if (lazy_on && criterion == ALGP_CRIT_ENTROPY && !forced && !ut_out && k > 0 && c->solved && c->prior_noise && c->M > 0)
+            return greedy_lazy(c, static_std, mobile_std, k, picks_out);
         for (int pck = 0; pck < k; ++pck) {
             ALGP_TRY(scores(c, criterion, static_std, mobile_std, ut_out ? ut_out + (int64_t)pck * c->M : nullptr, 0));
             int64_t pool_idx;
@@ -1193,7 +1290,7 @@ void algp_destroy(algp_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
-                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);

