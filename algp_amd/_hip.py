@@ -60,6 +60,7 @@ SIGNATURES = {
     'algp_posterior_mean': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p]),
     'algp_scores': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int]),
     'algp_argmax': (C.c_int, [_c_ctx, _i64p, _i64p, _dblp]),
+    'algp_best_candidate': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, _i64p, _i64p, _dblp]),
     'algp_commit_pick': (C.c_int, [_c_ctx, C.c_int64, C.c_double, C.c_double]),
     'algp_greedy': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_int, _i64p, _i64p, _dblp]),
     'algp_entropy_from_cov': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, _dblp]),
@@ -304,6 +305,14 @@ class Context(object):
     def argmax(self):
         pos, pool, val = C.c_int64(), C.c_int64(), C.c_double()
         self._check(self.lib.algp_argmax(self.h, C.byref(pos), C.byref(pool), C.byref(val)))
+        return pos.value, pool.value, val.value
+
+    def best_candidate(self, criterion, static_std, mobile_std):
+        """(local position, pool index, utility) of the first maximum; rows are brought up to date with the
+        committed picks only as far as needed (algp_best_candidate)."""
+        pos, pool, val = C.c_int64(), C.c_int64(), C.c_double()
+        self._check(self.lib.algp_best_candidate(self.h, int(criterion), float(static_std), float(mobile_std),
+                                                 C.byref(pos), C.byref(pool), C.byref(val)))
         return pos.value, pool.value, val.value
 
     def commit_pick(self, pool_idx, static_std, mobile_std):

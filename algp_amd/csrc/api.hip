@@ -525,7 +525,7 @@ struct Impl {
         ALGP_TRY(sync(c));
         c->ncols = Npad;
         c->picks.clear();
-        c->lazy_stale = false;
+        ALGP_TRY(reset_lazy(c));
         c->solved = true;
         c->vt_fact_idx = c->fact_idx;
         c->vt_fact_var = c->fact_var;
@@ -690,7 +690,7 @@ struct Impl {
         c->kept_rows_last = 0;
         c->ncols = Npad;
         c->picks.clear();
-        c->lazy_stale = false;
+        ALGP_TRY(reset_lazy(c));
         c->solved = true;
         c->vt_fact_idx = c->fact_idx;
         c->vt_fact_var = c->fact_var;
@@ -938,6 +938,10 @@ struct Impl {
         double* dst = out_is_device ? (double*)out : (double*)c->scores.p;
         ALGP_TRY(score_launch<T>(c, c->M, (const int*)c->ckind.p, (const unsigned char*)c->alive.p, (const T*)c->dstat.p,
                                  ss, delta, extra_dev, dst));
+        // entropy utilities of up-to-date rows: from here on c->scores can serve as upper bounds (lazy greedy)
+        c->bounds_valid = criterion == ALGP_CRIT_ENTROPY;
+        c->lazy_ss = ss;
+        c->lazy_delta = delta;
         if (out_is_device) {
             ALGP_HIP(hipMemcpyAsync(c->scores.p, dst, sizeof(double) * c->M, hipMemcpyDeviceToDevice, c->stream));
         } else if (out) {
@@ -1023,9 +1027,11 @@ struct Impl {
         return sync(c);
     }
 
+    // Make `pool_idx` static-sampled.  Only the pick is recorded (its row of V^T, its scale); the other rows
+    // of V^T / dstat catch up on demand (lazy_refresh_kernel) -- before anything reads the full state
+    // (flush_lazy) or, in best_candidate, only the rows that can still win.
     static int commit_pick(algp_ctx* c, int64_t pool_idx, double static_std, double mobile_std) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "commit_pick: call algp_solve_candidates first");
-        ALGP_TRY(flush_lazy(c));
         if (pool_idx < 0 || pool_idx >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: index outside the pool");
         if ((int64_t)c->picks.size() >= MAX_APPEND) return fail(c, ALGP_ERR_STATE, "commit_pick: append capacity exhausted; re-factorize");
         for (auto& pk : c->picks)
@@ -1035,8 +1041,10 @@ struct Impl {
         const int in_train = c->pos_in_train[pool_idx] >= 0 ? 1 : 0;
         const int64_t local = c->cand_pos[pool_idx];
         const int64_t ldv = c->ldv, ncols = c->ncols;
+        const size_t q = c->picks.size();
         double dc = 0;
         if (local >= 0) {
+            if (c->lazy_stale) ALGP_TRY(lazy_launch(c, 0, local, ss, delta));     // the winner's own row must be current
             ALGP_HIP(hipMemsetAsync(c->lrow.p, 0, sizeof(T) * ldv, c->stream));
             ALGP_HIP(hipMemcpyAsync(c->lrow.p, p(c->Vt) + local * ldv, sizeof(T) * ncols, hipMemcpyDeviceToDevice, c->stream));
             T dch;
@@ -1055,15 +1063,18 @@ struct Impl {
         }
         if (!(scale == scale) || isinf(scale))
             return fail(c, ALGP_ERR_NOT_PD, "commit_pick: posterior variance of the pick is not positive");
-        T* t = p(c->tvec);
-        ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), c->M, ldv, ncols, p(c->lrow), (T*)nullptr, t));
-        ALGP_TRY(pick_update_launch<T>(c, c->M, (const int*)c->ckind.p, (const int64_t*)c->Cidx.p, (const T*)c->Xs.p,
-                                       c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, c->hyp.DP, pool_idx,
-                                       in_train, c->hyp.kernel, (T)c->hyp.outputscale, (T)c->hyp.noise, t, (T)scale,
-                                       p(c->dstat), p(c->Vt), ldv, ncols));
-        ALGP_HIP(hipMemcpyAsync(p(c->prevrows) + (int64_t)c->picks.size() * ldv, c->lrow.p, sizeof(T) * ldv,
-                                hipMemcpyDeviceToDevice, c->stream));
-        if (local >= 0) ALGP_HIP(hipMemsetAsync((unsigned char*)c->alive.p + local, 0, 1, c->stream));
+        LazyPick lp;
+        lp.pool_idx = pool_idx;
+        lp.ncols = ncols;
+        lp.scale = scale;
+        lp.in_train = in_train;
+        static const double neg_inf = -INFINITY;
+        ALGP_HIP(hipMemcpyAsync(p(c->prevrows) + (int64_t)q * ldv, c->lrow.p, sizeof(T) * ldv, hipMemcpyDeviceToDevice, c->stream));
+        ALGP_HIP(hipMemcpyAsync((LazyPick*)c->lazypicks.p + q, &lp, sizeof(lp), hipMemcpyHostToDevice, c->stream));
+        if (local >= 0) {
+            ALGP_HIP(hipMemsetAsync((unsigned char*)c->alive.p + local, 0, 1, c->stream));
+            ALGP_HIP(hipMemcpyAsync((double*)c->scores.p + local, &neg_inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
         ALGP_TRY(sync(c));
         PickRec pr;
         pr.pool_idx = pool_idx;
@@ -1071,6 +1082,7 @@ struct Impl {
         pr.scale = scale;
         c->picks.push_back(pr);
         c->ncols = ncols + 1;
+        c->lazy_stale = true;
         return ALGP_OK;
     }
 
@@ -1083,6 +1095,15 @@ struct Impl {
                                       p(c->dstat), (int*)c->fresh.p, (const unsigned char*)c->alive.p,
                                       (double*)c->scores.p, ss, delta);
     }
+    // after a candidate solve: no picks, every row current, no bounds
+    static int reset_lazy(algp_ctx* c) {
+        ALGP_TRY(ensure(c, c->fresh, sizeof(int) * std::max<int64_t>(c->Mpad, 1)));
+        ALGP_TRY(ensure(c, c->lazypicks, sizeof(LazyPick) * MAX_APPEND));
+        ALGP_HIP(hipMemsetAsync(c->fresh.p, 0, sizeof(int) * std::max<int64_t>(c->Mpad, 1), c->stream));
+        c->lazy_stale = false;
+        c->bounds_valid = false;
+        return ALGP_OK;
+    }
     // bring every row of V^T / dstat up to date with the committed picks (stream-ordered, no host sync)
     static int flush_lazy(algp_ctx* c) {
         if (!c->lazy_stale) return ALGP_OK;
@@ -1091,87 +1112,46 @@ struct Impl {
         return ALGP_OK;
     }
 
-    // commit the local candidate `local` without touching the other rows (they catch up on demand)
-    static int commit_lazy(algp_ctx* c, int64_t local, double ss, double delta) {
-        const int64_t pool_idx = c->cand_idx[local];
-        if ((int64_t)c->picks.size() >= MAX_APPEND) return fail(c, ALGP_ERR_STATE, "commit_pick: append capacity exhausted; re-factorize");
-        for (auto& pk : c->picks)
-            if (pk.pool_idx == pool_idx) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: site already static-sampled");
-        const int in_train = c->pos_in_train[pool_idx] >= 0 ? 1 : 0;
-        const int64_t ldv = c->ldv, ncols = c->ncols;
-        const size_t q = c->picks.size();
-        T* prev = p(c->prevrows) + (int64_t)q * ldv;
-        ALGP_HIP(hipMemsetAsync(prev, 0, sizeof(T) * ldv, c->stream));
-        ALGP_HIP(hipMemcpyAsync(prev, p(c->Vt) + local * ldv, sizeof(T) * ncols, hipMemcpyDeviceToDevice, c->stream));
-        T dch;
-        ALGP_HIP(hipMemcpyAsync(&dch, p(c->dstat) + local, sizeof(T), hipMemcpyDeviceToHost, c->stream));
-        ALGP_TRY(sync(c));
-        const double dc = (double)dch;
-        const double scale = in_train ? sqrt(-(delta / (1.0 + delta * dc))) : 1.0 / sqrt(dc + ss);
-        if (!(scale == scale) || isinf(scale))
-            return fail(c, ALGP_ERR_NOT_PD, "commit_pick: posterior variance of the pick is not positive");
-        LazyPick lp;
-        lp.pool_idx = pool_idx;
-        lp.ncols = ncols;
-        lp.scale = scale;
-        lp.in_train = in_train;
-        static const double neg_inf = -INFINITY;
-        ALGP_HIP(hipMemcpyAsync((LazyPick*)c->lazypicks.p + q, &lp, sizeof(lp), hipMemcpyHostToDevice, c->stream));
-        ALGP_HIP(hipMemsetAsync((unsigned char*)c->alive.p + local, 0, 1, c->stream));
-        ALGP_HIP(hipMemcpyAsync((double*)c->scores.p + local, &neg_inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
-        ALGP_TRY(sync(c));
-        PickRec pr;
-        pr.pool_idx = pool_idx;
-        pr.in_train = in_train;
-        pr.scale = scale;
-        c->picks.push_back(pr);
-        c->ncols = ncols + 1;
-        c->lazy_stale = true;
-        return ALGP_OK;
-    }
-
-    static int greedy_lazy(algp_ctx* c, double static_std, double mobile_std, int k, int64_t* picks_out) {
+    // The best local candidate under the current state.  Entropy criterion: c->scores holds, per row, the
+    // utility as of the picks applied to that row -- an upper bound of the current one -- and only the rows
+    // that can still win are brought up to date.  MI: full scoring (its complement terms change with every pick).
+    static int best_candidate(algp_ctx* c, int criterion, double static_std, double mobile_std, int64_t* local_pos,
+                              int64_t* pool_idx, double* value) {
+        if (!c->solved) return fail(c, ALGP_ERR_STATE, "best_candidate: call algp_solve_candidates first");
+        if (c->M == 0) return fail(c, ALGP_ERR_BAD_ARG, "best_candidate: empty candidate set");
         const double ss = static_std * static_std, sm = mobile_std * mobile_std;
         const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
-        // full utilities once (flushes rows left stale by an earlier call); from here on c->scores holds,
-        // per row, the utility as of the picks applied to that row -- an upper bound of the current one
-        ALGP_TRY(scores(c, ALGP_CRIT_ENTROPY, static_std, mobile_std, nullptr, 0));
-        ALGP_TRY(ensure(c, c->fresh, sizeof(int) * c->Mpad));
-        ALGP_TRY(ensure(c, c->lazypicks, sizeof(LazyPick) * MAX_APPEND));
-        ALGP_HIP(hipMemsetD32Async((hipDeviceptr_t)c->fresh.p, (int)c->picks.size(), (size_t)c->Mpad, c->stream));
-        c->lazy_ss = ss;
-        c->lazy_delta = delta;
-        for (int pck = 0; pck < k; ++pck) {
-            int64_t pos;
-            for (;;) {
-                ALGP_TRY(argmax(c, &pos, nullptr, nullptr));
-                if (pos < 0) return fail(c, ALGP_ERR_BAD_ARG, "greedy: every utility is NaN");
-                if (!c->lazy_stale) break;                            // nothing committed since the full scoring
-                int f;
-                ALGP_HIP(hipMemcpyAsync(&f, (const int*)c->fresh.p + pos, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                ALGP_TRY(sync(c));
-                if (f >= (int)c->picks.size()) break;                 // the maximum is an up-to-date row: it wins
-                ALGP_TRY(lazy_launch(c, 0, pos, ss, delta));          // the best bound becomes a true value ...
-                ALGP_TRY(lazy_launch(c, 1, pos, ss, delta));          // ... and every bound reaching it is resolved
-            }
-            if (picks_out) picks_out[pck] = c->cand_idx[pos];
-            ALGP_TRY(commit_lazy(c, pos, ss, delta));
+        static const bool lazy_on = !(getenv("ALGP_LAZY_GREEDY") && atoi(getenv("ALGP_LAZY_GREEDY")) == 0);
+        if (criterion != ALGP_CRIT_ENTROPY || !lazy_on || !c->bounds_valid || c->lazy_ss != ss || c->lazy_delta != delta)
+            ALGP_TRY(scores(c, criterion, static_std, mobile_std, nullptr, 0));      // flushes, scores every row
+        int64_t pos;
+        double val;
+        for (;;) {
+            ALGP_TRY(argmax(c, &pos, nullptr, &val));
+            if (pos < 0 || !c->lazy_stale) break;                 // all NaN, or nothing committed since the full scoring
+            int f;
+            ALGP_HIP(hipMemcpyAsync(&f, (const int*)c->fresh.p + pos, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            ALGP_TRY(sync(c));
+            if (f >= (int)c->picks.size()) break;                 // the maximum is an up-to-date row: it wins
+            ALGP_TRY(lazy_launch(c, 0, pos, ss, delta));          // the best bound becomes a true value ...
+            ALGP_TRY(lazy_launch(c, 1, pos, ss, delta));          // ... and every bound reaching it is resolved
         }
+        if (local_pos) *local_pos = pos;
+        if (pool_idx) *pool_idx = pos >= 0 ? c->cand_idx[pos] : -1;
+        if (value) *value = val;
         return ALGP_OK;
     }
 
     static int greedy(algp_ctx* c, int criterion, double static_std, double mobile_std, int k, const int64_t* forced,
                       int64_t* picks_out, double* ut_out) {
-        static const bool lazy_on = !(getenv("ALGP_LAZY_GREEDY") && atoi(getenv("ALGP_LAZY_GREEDY")) == 0);
-        if (lazy_on && criterion == ALGP_CRIT_ENTROPY && !forced && !ut_out && k > 0 && c->solved && c->prior_noise && c->M > 0)
-            return greedy_lazy(c, static_std, mobile_std, k, picks_out);
         for (int pck = 0; pck < k; ++pck) {
-            ALGP_TRY(scores(c, criterion, static_std, mobile_std, ut_out ? ut_out + (int64_t)pck * c->M : nullptr, 0));
             int64_t pool_idx;
-            if (forced) {
-                pool_idx = forced[pck];
+            if (ut_out || forced) {
+                ALGP_TRY(scores(c, criterion, static_std, mobile_std, ut_out ? ut_out + (int64_t)pck * c->M : nullptr, 0));
+                if (forced) pool_idx = forced[pck];
+                else ALGP_TRY(argmax(c, nullptr, &pool_idx, nullptr));
             } else {
-                ALGP_TRY(argmax(c, nullptr, &pool_idx, nullptr));
+                ALGP_TRY(best_candidate(c, criterion, static_std, mobile_std, nullptr, &pool_idx, nullptr));
             }
             if (picks_out) picks_out[pck] = pool_idx;
             ALGP_TRY(commit_pick(c, pool_idx, static_std, mobile_std));
@@ -1453,6 +1433,7 @@ int algp_set_candidate_alive(algp_ctx* c, const uint8_t* alive) {
     if (!c->solved || !alive) return fail(c, ALGP_ERR_STATE, "set_candidate_alive: solve the candidates first");
     if (hipMemcpyAsync(c->alive.p, alive, c->M, hipMemcpyHostToDevice, c->stream) != hipSuccess)
         return fail(c, ALGP_ERR_HIP, "set_candidate_alive: copy failed");
+    c->bounds_valid = false;            // a re-enabled row has no bound in c->scores
     return sync(c);
 }
 int algp_get_posterior(algp_ctx* c, void* mu, void* var) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_posterior(c, mu, var))); }
@@ -1472,6 +1453,11 @@ int algp_scores(algp_ctx* c, int criterion, double static_std, double mobile_std
 int algp_argmax(algp_ctx* c, int64_t* local_pos, int64_t* pool_idx, double* value) {
     CHECK_CTX(c);
     FINISH(c, DISPATCH(c, argmax(c, local_pos, pool_idx, value)));
+}
+int algp_best_candidate(algp_ctx* c, int criterion, double static_std, double mobile_std, int64_t* local_pos,
+                        int64_t* pool_idx, double* value) {
+    CHECK_CTX(c);
+    FINISH(c, DISPATCH(c, best_candidate(c, criterion, static_std, mobile_std, local_pos, pool_idx, value)));
 }
 int algp_commit_pick(algp_ctx* c, int64_t pool_idx, double static_std, double mobile_std) {
     CHECK_CTX(c);

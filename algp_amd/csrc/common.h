@@ -107,6 +107,7 @@ struct algp_ctx {
     // lazy greedy: fresh[j] = number of committed picks already applied to row j of V^T / dstat[j]
     algp::DevBuf fresh, lazypicks;
     bool lazy_stale = false;             // some rows lag behind picks.size(): flush before reading the full state
+    bool bounds_valid = false;           // c->scores = entropy utility of each row as of fresh[row] picks, for (lazy_ss, lazy_delta)
     double lazy_ss = 0, lazy_delta = 0;
     bool solved = false;
     int64_t ldv_cap = 0;                 // allocated leading dimension of V^T

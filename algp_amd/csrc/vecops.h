@@ -10,10 +10,6 @@ template <typename T>
 int score_launch(algp_ctx* c, int64_t M, const int* ckind, const unsigned char* alive, const T* dstat, double ss,
                  double delta, const double* extra, double* out);
 int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx);
-template <typename T>
-int pick_update_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
-                       int64_t n_pool, int DP, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
-                       const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col);
 // lazy greedy refresh (vecops.hip): mode 0 = row pos, 1 = stale rows whose bound reaches scores[pos], 2 = all stale
 template <typename T>
 int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const LazyPick* picks, int npicks, const int* ckind,

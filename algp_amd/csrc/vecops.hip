@@ -182,7 +182,7 @@ int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int6
 }
 
 // ---------------------------------------------------------------------------------------------
-// greedy commit: r_j = (b'_j - t_j) * scale ; dstat_j -= r^2 (ordinary) / += r^2 (unit row);
+// greedy commit, per row j: r_j = (b'_j - V_j . l) * scale ; dstat_j -= r^2 (ordinary) / += r^2 (unit row);
 // V^T[j][ncols] = r_j.   b'_j = C(pick, j) when the pick is a new site and row j is ordinary.
 // ---------------------------------------------------------------------------------------------
 // b'_j = C(pick, j) when the pick is a new site and row j is ordinary, else 0
@@ -210,43 +210,6 @@ __device__ __forceinline__ T pick_bprime(bool unit, int64_t pj, const T* Xs, con
     }
     return bp;
 }
-
-template <typename T, int DP>
-__global__ void pick_update_kernel(int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
-                                   int64_t n_pool, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
-                                   const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    const bool unit = ckind[j] >= 0;
-    const T bp = pick_bprime<T, DP>(unit, cidx[j], Xs, Cp, n_pool, pick_pool, pick_in_train, kernel, os, noise);
-    const T r = (bp - tvec[j]) * scale;
-    dstat[j] += unit ? r * r : -(r * r);
-    Vt[j * ldv + col] = r;
-}
-
-template <typename T>
-int pick_update_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const T* Xs, const T* Cp,
-                       int64_t n_pool, int DP, int64_t pick_pool, int pick_in_train, int kernel, T os, T noise,
-                       const T* tvec, T scale, T* dstat, T* Vt, int64_t ldv, int64_t col) {
-    if (M <= 0) return ALGP_OK;
-    ProfScope ps(c, ALGP_PROF_ROWS, 8.0 * M, 4.0 * sizeof(T) * M);
-    dim3 grid((unsigned)((M + 255) / 256)), blk(256);
-#define ALGP_PU(DPV)                                                                                            \
-    hipLaunchKernelGGL((pick_update_kernel<T, DPV>), grid, blk, 0, c->cur, M, ckind, cidx, Xs, Cp, n_pool, \
-                       pick_pool, pick_in_train, kernel, os, noise, tvec, scale, dstat, Vt, ldv, col)
-    if (DP == 2) ALGP_PU(2);
-    else if (DP == 4) ALGP_PU(4);
-    else ALGP_PU(8);
-#undef ALGP_PU
-    ALGP_HIP(hipGetLastError());
-    return ALGP_OK;
-}
-template int pick_update_launch<double>(algp_ctx*, int64_t, const int*, const int64_t*, const double*, const double*,
-                                        int64_t, int, int64_t, int, int, double, double, const double*, double, double*,
-                                        double*, int64_t, int64_t);
-template int pick_update_launch<float>(algp_ctx*, int64_t, const int*, const int64_t*, const float*, const float*,
-                                       int64_t, int, int64_t, int, int, float, float, const float*, float, float*, float*,
-                                       int64_t, int64_t);
 
 // ---------------------------------------------------------------------------------------------
 // Lazy greedy (entropy criterion).  The gain of a candidate never grows when more sites are sampled

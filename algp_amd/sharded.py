@@ -5,11 +5,14 @@ the factor of the sampled set, so candidates shard embarrassingly:
 
   * every rank holds the full factor L of the train set (factorised redundantly, no comms),
   * rank r owns a contiguous slice of the candidate list and its V^T rows,
-  * per pick: local utilities -> ONE all-gather of the per-shard score vectors (RCCL over xGMI
-    when the backend is "nccl") -> the same first-max argmax on every rank (np.argmax semantics,
-    agent.py:349) -> every rank commits the global winner to its own shard.  A rank that does
-    not own the winner rebuilds the winner's row from the replicated factor
-    (algp_commit_pick), so no second collective is needed.
+  * per pick: ONE all-gather (RCCL over xGMI when the backend is "nccl") -> the same first-max
+    argmax on every rank (np.argmax semantics, agent.py:349) -> every rank commits the global
+    winner to its own shard.  A rank that does not own the winner rebuilds the winner's row from
+    the replicated factor (algp_commit_pick), so no second collective is needed.
+    What is gathered: with the entropy criterion each rank resolves its own best candidate lazily
+    (algp_best_candidate: only the rows whose upper bound can still win are brought up to date) and
+    contributes the pair (utility, global position) -- 16 bytes per rank; otherwise (MI, or a
+    backend without best_candidate) the per-shard score vectors as before.
 
 ``backend`` is any object with the `_hip.Context` scoring surface (scores / commit_pick / M);
 tests drive the same logic over gloo with a CPU stand-in backend.
@@ -32,6 +35,9 @@ class LocalComm(object):
 
     def all_gather(self, local, max_len):
         return local[None, :]
+
+    def all_gather_pairs(self, value, position):
+        return np.array([[value, position]], dtype=np.float64)
 
 
 class TorchComm(object):
@@ -64,6 +70,17 @@ class TorchComm(object):
             send[:len(local)] = self.torch.from_numpy(np.ascontiguousarray(local))
         self.dist.all_gather_into_tensor(recv.view(-1), send)
         return recv if self.device_buffers else recv.numpy()
+
+    def all_gather_pairs(self, value, position):
+        """(world, 2) array of every rank's (value, position); exact for positions < 2**53."""
+        t = self.torch
+        dev = self.device if self.device_buffers else 'cpu'
+        if getattr(self, '_pair_send', None) is None:
+            self._pair_send = t.empty(2, dtype=t.float64, device=dev)
+            self._pair_recv = t.empty((self.world_size, 2), dtype=t.float64, device=dev)
+        self._pair_send.copy_(t.tensor([float(value), float(position)], dtype=t.float64))
+        self.dist.all_gather_into_tensor(self._pair_recv.view(-1), self._pair_send)
+        return self._pair_recv.cpu().numpy()
 
     def first_max(self, g, parts):
         """(global position, value) of the first maximum in rank order (np.argmax semantics,
@@ -101,8 +118,9 @@ class ShardedGreedy(object):
     slice as its candidates (set_candidates + solve_candidates done).
     """
 
-    def __init__(self, backend, comm, all_cand_idx):
+    def __init__(self, backend, comm, all_cand_idx, lazy=True):
         self.b = backend
+        self.lazy = lazy                              # entropy criterion (0): gather (utility, position) pairs
         self.comm = comm
         self.all_idx = np.ascontiguousarray(all_cand_idx, dtype=np.int64)
         self.parts = partition(len(self.all_idx), comm.world_size)
@@ -120,8 +138,29 @@ class ShardedGreedy(object):
             return self.comm.all_gather(None, self.max_len)
         return self.comm.all_gather(self.b.scores(criterion, static_std, mobile_std), self.max_len)
 
+    def _step_pairs(self, criterion, static_std, mobile_std):
+        """Each rank resolves its own best candidate; the winners are compared, first maximum in rank order."""
+        if self.hi > self.lo:
+            pos, _, val = self.b.best_candidate(criterion, static_std, mobile_std)
+            if pos < 0 or val != val:
+                pos, val = 0, -np.inf
+        else:
+            pos, val = -1, -np.inf                    # a rank without candidates never wins
+        pairs = self.comm.all_gather_pairs(val, self.lo + pos if pos >= 0 else -1)
+        best_pos, best_v = -1, -np.inf
+        for r in range(len(pairs)):
+            v, gp = float(pairs[r, 0]), int(pairs[r, 1])
+            if gp >= 0 and (best_pos < 0 or v > best_v):
+                best_v, best_pos = v, gp
+        return best_pos, best_v
+
     def step(self, criterion, static_std, mobile_std):
         """One pick: returns (pool index of the winner, its utility)."""
+        if self.lazy and criterion == 0 and hasattr(self.b, 'best_candidate') and hasattr(self.comm, 'all_gather_pairs'):
+            best_pos, best_v = self._step_pairs(criterion, static_std, mobile_std)
+            winner = int(self.all_idx[best_pos])
+            self.b.commit_pick(winner, static_std, mobile_std)
+            return winner, best_v
         g = self._gather_scores(criterion, static_std, mobile_std)
         if hasattr(self.comm, 'first_max') and not isinstance(g, np.ndarray):
             best_pos, best_v = self.comm.first_max(g, self.parts)

@@ -148,15 +148,22 @@ int algp_posterior_mean(algp_ctx* ctx, const int64_t* idx, int64_t M, void* mu_o
  *   out: M doubles; out_is_device != 0 -> `out` is a device pointer (multi-GPU all-gather
  *   buffers owned by the caller).  Committed candidates get -inf (agent.py:314, 318).
  * algp_argmax: first maximum (np.argmax, agent.py:349) over the local scores.
- * algp_commit_pick: make pool index `pool_idx` static-sampled (agent.py:352-354) and apply the
- *   rank-1 row append to V^T and to every candidate's pv / s.  The index need not be a local
- *   candidate (sharded scoring: every rank commits the global winner).
+ * algp_best_candidate: the local first maximum of the utilities without scoring every row again.
+ *   Entropy gains never grow when more sites are sampled (submodularity), so a utility computed
+ *   before the last picks is an upper bound; only the rows whose bound can still win are brought
+ *   up to date.  Same winner and value as algp_scores + algp_argmax, bit for bit.  (MI: full scoring.)
+ * algp_commit_pick: make pool index `pool_idx` static-sampled (agent.py:352-354): the rank-1 row
+ *   append to V^T and to every candidate's pv / s.  The pick is recorded and the rows catch up on
+ *   demand (all of them before algp_scores / algp_get_posterior read them).  The index need not be
+ *   a local candidate (sharded scoring: every rank commits the global winner).
  * algp_greedy: k picks on one GPU.  utilities_out (k*M doubles, local candidate order) may be
  *   NULL; forced_picks (k pool indices) may be NULL.
  * MI criterion (agent.py:330-339) is exact and single-GPU: it needs the pool-wide complement. */
 int algp_scores(algp_ctx* ctx, int criterion, double static_std, double mobile_std, void* out,
                 int out_is_device);
 int algp_argmax(algp_ctx* ctx, int64_t* local_pos, int64_t* pool_idx, double* value);
+int algp_best_candidate(algp_ctx* ctx, int criterion, double static_std, double mobile_std,
+                        int64_t* local_pos, int64_t* pool_idx, double* value);
 int algp_commit_pick(algp_ctx* ctx, int64_t pool_idx, double static_std, double mobile_std);
 int algp_greedy(algp_ctx* ctx, int criterion, double static_std, double mobile_std, int k,
                 const int64_t* forced_picks, int64_t* picks_out, double* utilities_out);

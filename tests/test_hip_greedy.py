@@ -206,8 +206,9 @@ def test_fit_and_solve_pipeline_equals_separate_calls(dtname, pipeline, monkeypa
 @pytest.mark.parametrize('mode', ['coords', 'cov'])
 @pytest.mark.parametrize('dtname', ['f64', 'f32'])
 def test_lazy_greedy_equals_full_pass(dtname, mode):
-    """algp_greedy without utilities takes the lazy route (only rows that can still win are brought up to
-    date after a pick); picks, and the state after the flush, must equal the full pass bit for bit."""
+    """algp_greedy without utilities resolves each pick with algp_best_candidate (only rows that can still win
+    are brought up to date after a pick); picks, and the state once every row has caught up, must equal the
+    loop that scores every row before every pick, bit for bit."""
     dt = np.float64 if dtname == 'f64' else np.float32
     c = _hip.Context(dt)
     rng = np.random.RandomState(5)
@@ -236,7 +237,15 @@ def test_lazy_greedy_equals_full_pass(dtname, mode):
         c.commit_pick(w, 0.1, 1.0)
     s_full = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
     var_full = c.posterior()[1]
-    assert np.any(mobile[full_picks]) or True
+    # algp_best_candidate on its own: same winner and value as scores + argmax, at every step
+    _setup_state(c, static, mobile, 0.01, 1.0)
+    for w_full in full_picks[:5]:
+        pos, w, val = c.best_candidate(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        assert w == w_full and cand[pos] == w
+        c.commit_pick(w, 0.1, 1.0)
+    pos, w, val = c.best_candidate(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    assert w == full_picks[5] and val == s[pos] == np.max(s)
     _setup_state(c, static, mobile, 0.01, 1.0)
     lazy_picks = list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4))
     lazy_picks += list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, k - 4))      # a second call continues from stale rows

@@ -89,6 +89,10 @@ class OracleBackend(object):
         with np.errstate(all='ignore'):
             u = np.where(self.in_A, .5 * np.log1p(self.delta * self.d), O.CONST + .5 * np.log(self.d + self.ss))
         return np.where(self.alive, u, -np.inf)
+    def best_candidate(self, criterion, static_std, mobile_std):
+        s = self.scores(criterion, static_std, mobile_std)
+        j = int(np.argmax(s))
+        return j, int(self.cand[j]), float(s[j])
     def commit_pick(self, pool_idx, static_std, mobile_std):
         in_tr = self.pos[pool_idx] >= 0
         l = self._col(pool_idx)[:, 0]
@@ -116,12 +120,14 @@ static = np.zeros(len(X), bool); mobile = np.zeros(len(X), bool)
 perm = rng.permutation(len(X)); static[perm[:40]] = True; mobile[perm[30:90]] = True
 cand = np.where(~static)[0]
 lo, hi = partition(len(cand), world)[rank]
-backend = OracleBackend(C, static, mobile, cand[lo:hi], 0.01, 1.0)
-sg = ShardedGreedy(backend, TorchComm(), cand)
-picks, vals = sg.greedy(0, 0.1, 1.0, 5)
 want, ut = O.greedy_fast(C, static, mobile, 0.1, 1.0, 5, 'entropy')
-assert picks == want, (picks, want)
-assert np.allclose(vals, [ut[p][want[p]] for p in range(5)], rtol=1e-9)
+comm = TorchComm()
+for lazy in (True, False):          # (utility, position) pairs | whole score vectors
+    backend = OracleBackend(C, static, mobile, cand[lo:hi], 0.01, 1.0)
+    sg = ShardedGreedy(backend, comm, cand, lazy=lazy)
+    picks, vals = sg.greedy(0, 0.1, 1.0, 5)
+    assert picks == want, (lazy, picks, want)
+    assert np.allclose(vals, [ut[p][want[p]] for p in range(5)], rtol=1e-9)
 if rank == 0:
     print('SHARDED_OK', picks)
 dist.destroy_process_group()

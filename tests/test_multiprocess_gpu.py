@@ -38,9 +38,12 @@ def make(idx_slice):
     return c
 
 lo, hi = partition(len(cand), world)[rank]
+comm = TorchComm()
 c = make(cand[lo:hi])
-sg = ShardedGreedy(c, TorchComm(), cand)
-picks, vals = sg.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)
+picks, vals = ShardedGreedy(c, comm, cand).greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)    # (utility, position) pairs
+c.factorize(); c.solve_candidates()
+picks_v, vals_v = ShardedGreedy(c, comm, cand, lazy=False).greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)   # score vectors
+assert picks_v == picks and vals_v == vals, (picks_v, picks)
 if rank == 0:
     full = make(cand)
     p2, ut = full.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
