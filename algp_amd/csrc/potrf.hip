@@ -431,7 +431,7 @@ static int cholesky_serial(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD,
             // trailing update with the whole block: A22 -= P_blk P_blk^T, K = w, lower tiles
             const T* Pb = A + (j0 + w) * ld + j0;
             T* A22 = A + (j0 + w) * ld + (j0 + w);
-            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, mrem, mrem, w, (T)-1, Pb, ld, Pb, ld, (T)1, A22, ld,
+            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL_UPDATE, mrem, mrem, w, (T)-1, Pb, ld, Pb, ld, (T)1, A22, ld,
                                        A22, ld, 1));
         }
     }

@@ -236,6 +236,8 @@ def main():
             except Exception:
                 traffic = None
         gc = prof['gemm_chol']
+        gu = prof['gemm_chol_update']
+        gu_tf = gu['flops'] / (gu['ms'] * 1e-3) / 1e12 if gu['ms'] > 0 else 0.0
         chol_ms = prof['cholesky']['ms'] / args.steps            # wall time of the factorisation (two overlapped streams)
         chol_tf = (N ** 3 / 3.0) / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
         out = {
@@ -249,7 +251,7 @@ def main():
             'config': {'workload': '%d-point MoG field (train) x %d candidates/GPU, %d greedy picks, entropy criterion, D=2'
                                    % (N, per, args.picks),
                        'n_train': N, 'candidates_per_gpu': per, 'candidates_total': total_c,
-                       'parallelism': 'candidate shards x%d, one all-gather of scores per pick' % world},
+                       'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + position)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel<%s> (candidate TRSM)' % ('double' if args.dtype == 'f64' else 'float'),
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                          'traffic': traffic, 'launches': g['launches'], 'avg_launch_ms': g['ms'] / max(1, g['launches']),
@@ -257,7 +259,10 @@ def main():
                          'note': 'launches of the two row halves overlap on two streams: achieved = flops / wall time of the solves',
                          'flops_per_launch': g['flops'] / max(1, g['launches'])},
             'cholesky_tflops': chol_tf, 'cholesky_ms': chol_ms,
-            'cholesky_gemm_tflops': gc['flops'] / (gc['ms'] * 1e-3) / 1e12 if gc['ms'] > 0 else 0.0,
+            'cholesky_gemm_tflops': (gc['flops'] + gu['flops']) / ((gc['ms'] + gu['ms']) * 1e-3) / 1e12 if gc['ms'] + gu['ms'] > 0 else 0.0,
+            # the factorisation's dense rank-512 trailing ("panel") updates on MFMA, HIP-event time of those launches
+            'cholesky_panel_update': {'achieved': gu_tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': gu_tf / peak,
+                                      'launches': gu['launches'], 'ms_per_step': gu['ms'] / args.steps},
             'stage_ms_per_step': {k: v['ms'] / args.steps for k, v in prof.items()},
             'picks_last_step': picks_log[-1],
         }

@@ -58,7 +58,9 @@ enum {
     ALGP_PROF_GEMM_OTHER = 7,
     ALGP_PROF_CHOLESKY = 8,    /* wall time of whole train-set factorisations (two overlapped streams) */
     ALGP_PROF_TRSM = 9,        /* wall time of whole candidate solves (two overlapped streams)        */
-    ALGP_PROF_COUNT = 10
+    ALGP_PROF_GEMM_CHOL_UPDATE = 10, /* the Cholesky's K=512 trailing (rank-512) updates, a subset of GEMM_CHOL's work
+                                      * counted here instead: the "dense panel update" of the blocked factorisation */
+    ALGP_PROF_COUNT = 11
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
