@@ -114,28 +114,38 @@ class Agent(object):
         self.collected['y'] += ys
 
     # ---- fusion of repeated readings (agent.py:92-117) --------------------------------------------
+    def _site_means(self):
+        """Counts and np.mean of the static / mobile readings of every site.  The reference walks all n sites
+        and calls np.mean twice per sampled one at every planning step (agent.py:97-109); here a mean is
+        re-evaluated only for a site whose reading list changed since the last call (same values, O(changes))."""
+        n = self.env.num_samples
+        cache = getattr(self, '_mean_cache', None)
+        if cache is None or cache['n'] != n:
+            cache = dict(n=n, cnt=[np.zeros(n, np.int64), np.zeros(n, np.int64)],
+                         ids=[np.zeros(n, np.int64), np.zeros(n, np.int64)], mean=[np.zeros(n), np.zeros(n)])
+            self._mean_cache = cache
+        for k, data in enumerate((self.static_data, self.mobile_data)):
+            cnt = np.fromiter(map(len, data), dtype=np.int64, count=n)
+            ids = np.fromiter(map(id, data), dtype=np.int64, count=n)
+            for i in np.nonzero((cnt != cache['cnt'][k]) | (ids != cache['ids'][k]))[0]:
+                cache['mean'][k][i] = np.mean(data[i]) if cnt[i] else 0.0
+            cache['cnt'][k], cache['ids'][k] = cnt, ids
+        return cache['cnt'][0], cache['cnt'][1], cache['mean'][0], cache['mean'][1]
+
     def get_sampled_dataset(self):
         ss, sm = self.static_std ** 2, self.mobile_std ** 2
-        idx, ys, vs = [], [], []
-        for i in range(self.env.num_samples):
-            s, m = self.static_data[i], self.mobile_data[i]
-            if s and m:
-                y = (sm * np.mean(s) + ss * np.mean(m)) / (sm + ss)
-                v = 1 / (1 / ss + 1 / sm)
-            elif s:
-                y, v = np.mean(s), ss
-            elif m:
-                y, v = np.mean(m), sm
-            else:
-                continue
-            idx.append(i)
-            ys.append(y)
-            vs.append(v)
-        return idx, np.array(ys), np.array(vs)
+        cs, cm, ms, mm = self._site_means()
+        has_s, has_m = cs > 0, cm > 0
+        idx = np.nonzero(has_s | has_m)[0]
+        hs, hm = has_s[idx], has_m[idx]
+        ys = np.where(hs & hm, (sm * ms[idx] + ss * mm[idx]) / (sm + ss), np.where(hs, ms[idx], mm[idx]))
+        vs = np.where(hs & hm, 1 / (1 / ss + 1 / sm), np.where(hs, ss, sm))
+        return [int(i) for i in idx], ys, vs
 
     def _masks(self):
-        static = np.array([len(v) > 0 for v in self.static_data], dtype=bool)
-        mobile = np.array([len(v) > 0 for v in self.mobile_data], dtype=bool)
+        n = self.env.num_samples
+        static = np.fromiter(map(len, self.static_data), dtype=np.int64, count=n) > 0
+        mobile = np.fromiter(map(len, self.mobile_data), dtype=np.int64, count=n) > 0
         return static, mobile
 
     def _fused_var(self, static, mobile):

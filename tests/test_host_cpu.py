@@ -28,6 +28,17 @@ def test_get_sampled_dataset_matches_reference(golden):
     idx, y, var = a.get_sampled_dataset()
     assert idx == list(g['g5_idx'])
     assert np.allclose(y, g['g5_y'], rtol=1e-14, atol=0) and np.allclose(var, g['g5_var'], rtol=1e-14, atol=0)
+    # the per-site means are cached between calls: appended readings, a replaced list of the same length and a
+    # first reading at a new site must all show up
+    empty = [i for i in range(len(sd)) if not sd[i] and not md[i]]
+    full = [i for i in range(len(sd)) if sd[i]]
+    sd[full[0]].append(0.75)
+    md[full[1]].append(-0.5)
+    sd[full[2]] = [v + 1.0 for v in sd[full[2]]]
+    md[empty[0]].append(0.25)
+    idx2, y2, var2 = a.get_sampled_dataset()
+    idx_o, y_o, var_o = O.get_sampled_dataset_ref(sd, md, 0.1, 1.0)
+    assert idx2 == [int(i) for i in idx_o] and np.array_equal(y2, y_o) and np.array_equal(var2, var_o)
 
 
 def test_synthetic_field_generator_matches_reference(golden):
