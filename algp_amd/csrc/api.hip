@@ -297,8 +297,10 @@ struct Impl {
     }
 
     // make room for an Npad x Npad factor with leading dimension Lld >= Npad, keeping the first
-    // `keep_rows` rows (and their inverse diagonal blocks) when the buffers have to grow
-    static int reserve_factor(algp_ctx* c, int64_t npad_need, int64_t keep_rows) {
+    // `keep_rows` rows (and their inverse diagonal blocks) when the buffers have to grow -- and, of the rows
+    // [keep_rows, keep_height), the part left of column keep_rows (rows of the partial last block whose
+    // solved entries against the kept blocks stay valid)
+    static int reserve_factor(algp_ctx* c, int64_t npad_need, int64_t keep_rows, int64_t keep_height = 0) {
         if (c->Lld >= npad_need && c->L.p && c->invD.p) return ALGP_OK;
         const int64_t newld = round_up(std::max<int64_t>(npad_need, c->Lld + c->Lld / 4), NB);
         DevBuf nl, ni;
@@ -307,7 +309,7 @@ struct Impl {
         if (rc != ALGP_OK) { release(c, nl); release(c, ni); return rc; }
         if (keep_rows > 0 && c->L.p) {
             hipError_t e = hipMemcpy2DAsync(nl.p, sizeof(T) * newld, c->L.p, sizeof(T) * c->Lld, sizeof(T) * keep_rows,
-                                            keep_rows, hipMemcpyDeviceToDevice, c->stream);
+                                            std::max(keep_rows, keep_height), hipMemcpyDeviceToDevice, c->stream);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(ni.p, c->invD.p, sizeof(T) * keep_rows * NB, hipMemcpyDeviceToDevice, c->stream);
             if (e != hipSuccess) { release(c, nl); release(c, ni); return fail(c, ALGP_ERR_HIP, hipGetErrorString(e)); }
@@ -326,18 +328,37 @@ struct Impl {
     // what they were computed for; only the rows from the first changed block on are rebuilt:
     //   rows R of S regenerated, X = S[R, 0:Nb] L[0:Nb,0:Nb]^-T, S_RR -= X X^T, chol(S_RR).
     // Appending k sites to N therefore costs O((128 + k) N^2) instead of O(N^3 / 3).
+    // Factor update: can the rows of the new train sites [p0, N) (left of the tail block, columns [0, Nb)) be
+    // taken from the resident V^T?  Needs V^T solved for the same kept blocks and hyper-parameters, the
+    // same candidate list, and every new site an ordinary candidate row.  src_row: V^T row per factor row
+    // p0 .. Npad-1 (-1 = padding row, zero).
+    static bool vt_rows_for_new_sites(algp_ctx* c, int64_t Nb, int64_t p0, std::vector<int64_t>& src_row) {
+        static const bool on = !(getenv("ALGP_FACTOR_FROM_VT") && atoi(getenv("ALGP_FACTOR_FROM_VT")) == 0);
+        const int64_t N = c->N, Npad = c->Npad;
+        if (!on || !c->Vt.p || c->vt_hyp_stamp != c->hyp_stamp || (int64_t)c->vt_fact_idx.size() < Nb || Nb <= 0) return false;
+        if (c->vt_cand_idx != c->cand_idx || (int64_t)c->vt_kind.size() != c->M) return false;
+        for (int64_t r = 0; r < Nb; ++r)
+            if (c->vt_fact_idx[r] != c->train_idx[r] || c->vt_fact_var[r] != c->train_var_host[r]) return false;
+        src_row.assign((size_t)(Npad - p0), -1);
+        for (int64_t i = p0; i < N; ++i) {
+            const int64_t j = c->cand_pos[c->train_idx[i]];
+            if (j < 0 || c->vt_kind[j] != -1) return false;
+            src_row[(size_t)(i - p0)] = j;
+        }
+        return true;
+    }
+
     static int factorize(algp_ctx* c, int incremental) {
         const int64_t N = c->N, Npad = c->Npad;
-        int64_t keep = 0;                                        // rows of the resident factor to keep
+        int64_t keep = 0, p0 = 0;                                // rows of the resident factor to keep; unchanged leading rows
         if (incremental && c->factored && c->fact_hyp_stamp == c->hyp_stamp && c->Lld > 0) {
             const int64_t lim = std::min<int64_t>(N, c->Nfact);
-            int64_t p0 = 0;
             while (p0 < lim && c->fact_idx[p0] == c->train_idx[p0] && c->fact_var[p0] == c->train_var_host[p0]) ++p0;
             keep = p0 / NB * NB;
         }
         c->factored = false;
         c->solved = false;
-        ALGP_TRY(reserve_factor(c, Npad, keep));
+        ALGP_TRY(reserve_factor(c, Npad, keep, p0));
         const int64_t ld = c->Lld;
         ALGP_TRY(ensure(c, c->z, sizeof(T) * Npad));
         ALGP_TRY(ensure(c, c->alpha, sizeof(T) * Npad));
@@ -354,12 +375,32 @@ struct Impl {
         } else {
             const int64_t Nb = keep, R = Npad - Nb;
             T* rows = p(c->L) + Nb * ld;
-            // regenerate rows [Nb, Npad) of S (all columns), identity on the padded diagonal
-            frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p + Nb, N - Nb, R, (const int64_t*)c->Aidx.p, N, Npad,
-                                 (const T*)c->varA.p + Nb, c->pool_is_cov ? 0 : 1, nullptr, 1, rows, ld, Nb);
-            // X = S[R, 0:Nb] L11^-T  (in place, against the kept blocks only)
-            if (frc == ALGP_OK)
-                frc = trsm_blocked<T>(c, ALGP_PROF_GEMM_CHOL, rows, R, ld, p(c->L), Nb, ld, p(c->invD));
+            // X = S[R, 0:Nb] L11^-T, the new rows of L left of the tail block.  A new train site that is a
+            // resident candidate already has this row: it is the leading part of its row of V^T (both are
+            // C[site, A] L^-T against the same kept blocks).  Then rows [Nb, p0) keep what they hold, rows
+            // [p0, N) are gathered from V^T and only the R x R tail block of S is regenerated -- no
+            // triangular solve against the kept factor (38 ms for 256 rows at N = 50 000).
+            std::vector<int64_t> src_row;
+            if (vt_rows_for_new_sites(c, Nb, p0, src_row)) {
+                frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p + Nb, N - Nb, R, (const int64_t*)c->Aidx.p + Nb, N - Nb, R,
+                                     (const T*)c->varA.p + Nb, c->pool_is_cov ? 0 : 1, nullptr, 1, rows + Nb, ld);
+                if (frc == ALGP_OK) frc = ensure(c, c->auxIdx, sizeof(int64_t) * std::max<size_t>(src_row.size(), 1));
+                if (frc == ALGP_OK && !src_row.empty()) {
+                    hipMemcpyAsync(c->auxIdx.p, src_row.data(), sizeof(int64_t) * src_row.size(), hipMemcpyHostToDevice, c->stream);
+                    frc = gather_rows_launch<T>(c, p(c->Vt), c->ldv, (const int64_t*)c->auxIdx.p, p(c->L) + p0 * ld, ld,
+                                                (int64_t)src_row.size(), Nb);
+                    if (frc == ALGP_OK) frc = sync(c);               // src_row is a host temporary
+                }
+                c->factor_rows_from_vt = (int64_t)src_row.size();
+            } else {
+                c->factor_rows_from_vt = 0;
+                // regenerate rows [Nb, Npad) of S (all columns), identity on the padded diagonal
+                frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p + Nb, N - Nb, R, (const int64_t*)c->Aidx.p, N, Npad,
+                                     (const T*)c->varA.p + Nb, c->pool_is_cov ? 0 : 1, nullptr, 1, rows, ld, Nb);
+                // X = S[R, 0:Nb] L11^-T  (in place, against the kept blocks only)
+                if (frc == ALGP_OK)
+                    frc = trsm_blocked<T>(c, ALGP_PROF_GEMM_CHOL, rows, R, ld, p(c->L), Nb, ld, p(c->invD));
+            }
             // S_RR -= X X^T
             if (frc == ALGP_OK)
                 frc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, R, R, Nb, (T)-1, rows, ld, rows, ld, (T)1, rows + Nb, ld,

@@ -93,6 +93,7 @@ struct algp_ctx {
     algp::DevBuf Aidx, yA, varA, y0, L, invD, z, alpha, scal;   // scal: device doubles (logdet, info...)
     double ybar = 0, logdet = 0, yalpha = 0;
     bool factored = false;
+    int64_t factor_rows_from_vt = 0;     // last factor update: rows of L taken from V^T instead of a triangular solve
     bool alpha_valid = false;            // alpha = L^-T z is computed on first use (scoring does not need it)
 
     // candidates

@@ -10,6 +10,9 @@ template <typename T>
 int score_launch(algp_ctx* c, int64_t M, const int* ckind, const unsigned char* alive, const T* dstat, double ss,
                  double delta, const double* extra, double* out);
 int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx);
+template <typename T>
+int gather_rows_launch(algp_ctx* c, const T* src, int64_t lds, const int64_t* src_row, T* dst, int64_t ldd, int64_t nrows,
+                       int64_t ncols);
 // lazy greedy refresh (vecops.hip): mode 0 = row pos, 1 = stale rows whose bound reaches scores[pos], 2 = all stale
 template <typename T>
 int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const LazyPick* picks, int npicks, const int* ckind,

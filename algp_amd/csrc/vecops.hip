@@ -211,6 +211,31 @@ __device__ __forceinline__ T pick_bprime(bool unit, int64_t pj, const T* Xs, con
     return bp;
 }
 
+// dst[r][0:ncols] = src[src_row[r]][0:ncols], or zeros where src_row[r] < 0 (one workgroup per row)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* src, int64_t lds, const int64_t* src_row, T* dst,
+                                                          int64_t ldd, int64_t ncols) {
+    const int64_t r = blockIdx.x, sr = src_row[r];
+    T* d = dst + r * ldd;
+    if (sr < 0) {
+        for (int64_t k = threadIdx.x; k < ncols; k += 256) d[k] = (T)0;
+    } else {
+        const T* sp = src + sr * lds;
+        for (int64_t k = threadIdx.x; k < ncols; k += 256) d[k] = sp[k];
+    }
+}
+
+template <typename T>
+int gather_rows_launch(algp_ctx* c, const T* src, int64_t lds, const int64_t* src_row, T* dst, int64_t ldd, int64_t nrows,
+                       int64_t ncols) {
+    if (nrows <= 0 || ncols <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((unsigned)nrows), dim3(256), 0, c->cur, src, lds, src_row, dst, ldd, ncols);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int gather_rows_launch<double>(algp_ctx*, const double*, int64_t, const int64_t*, double*, int64_t, int64_t, int64_t);
+template int gather_rows_launch<float>(algp_ctx*, const float*, int64_t, const int64_t*, float*, int64_t, int64_t, int64_t);
+
 // ---------------------------------------------------------------------------------------------
 // Lazy greedy (entropy criterion).  The gain of a candidate never grows when more sites are sampled
 // (information gain is submodular), so a utility computed before the last picks is an upper bound.  After

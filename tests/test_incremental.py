@@ -177,3 +177,65 @@ def test_candidate_solve_reuses_columns_and_matches_scratch():
     c.set_candidates(cand[:-1], prior_includes_noise=True)
     assert c.solve_candidates(incremental=True) == 0
     c.close()
+
+
+@pytest.mark.parametrize('dtname', ['f64', 'f32'])
+def test_factor_update_takes_new_rows_from_resident_candidates(dtname):
+    """New train sites that are resident (ordinary) candidates: their rows of L left of the tail block are the
+    leading parts of their rows of V^T, so the update gathers them instead of solving against the kept
+    factor.  Same factor as from scratch; the triangular solve's GEMM launches must be gone.  The factor
+    grows across a 128 boundary AND its buffer is re-allocated (rows of the partial last block survive)."""
+    dt = np.float64 if dtname == 'f64' else np.float32
+    tol = 1e-10 if dtname == 'f64' else 2e-3
+    rng = np.random.RandomState(2)
+    N0, M = 1000, 3000
+    X = rng.uniform(0, 60, (N0 + M, 2))
+    hyp = (np.log([3.0, 2.0]), 0.0, np.log(1e-2))
+    c = _hip.Context(dt)
+    c.set_hypers(*hyp)
+    c.set_pool(X)
+    idx, var = np.arange(N0), rng.choice([0.01, 1.0], N0)
+    cand = np.arange(N0 - 20, N0 + M)                       # 20 train sites are candidates too (unit rows)
+    c.set_train(idx, np.zeros(N0), var)
+    c.factorize(incremental=True)
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates(incremental=True)
+    c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)                # appended columns / stale rows must not matter
+    for step in range(3):
+        new = np.setdiff1d(cand[rng.permutation(len(cand))[:60]], idx)[:40]
+        idx = np.r_[idx, new]
+        var = np.r_[var, rng.choice([0.01, 1.0], len(new))]
+        c.set_train(idx, np.zeros(len(idx)), var)
+        c.prof_enable(True)
+        c.prof_reset()
+        kept = c.factorize(incremental=True)
+        launches = c.prof_get('gemm_chol')['launches']
+        c.prof_enable(False)
+        assert kept == (len(idx) - len(new)) // 128 * 128
+        assert launches <= 8, launches                      # Schur product + the small tail factorisation only
+        ref = _hip.Context(dt)
+        ref.set_hypers(*hyp)
+        ref.set_pool(X)
+        ref.set_train(idx, np.zeros(len(idx)), var)
+        ref.factorize()
+        L1, L2 = np.tril(c.factor()), np.tril(ref.factor())
+        assert np.max(np.abs(L1 - L2)) < tol * np.max(np.abs(L2))
+        assert abs(c.logdet() - ref.logdet()) < tol * abs(ref.logdet())
+        ref.close()
+        c.set_candidates(cand, prior_includes_noise=True)
+        c.solve_candidates(incremental=True)
+    # a new site that is NOT a candidate falls back to the triangular solve (and is still right)
+    c.set_candidates(cand[:-50], prior_includes_noise=True)
+    c.solve_candidates(incremental=True)
+    idx = np.r_[idx, cand[-1]]
+    var = np.r_[var, 0.01]
+    c.set_train(idx, np.zeros(len(idx)), var)
+    c.factorize(incremental=True)
+    ref = _hip.Context(dt)
+    ref.set_hypers(*hyp)
+    ref.set_pool(X)
+    ref.set_train(idx, np.zeros(len(idx)), var)
+    ref.factorize()
+    assert np.max(np.abs(np.tril(c.factor()) - np.tril(ref.factor()))) < tol
+    ref.close()
+    c.close()
