@@ -263,6 +263,12 @@ struct Impl {
         ALGP_TRY(ensure(c, c->varA, sizeof(T) * Npad));
         if (N > 0) ALGP_HIP(hipMemcpyAsync(c->Aidx.p, idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, c->stream));
         ALGP_HIP(hipMemcpyAsync(c->y0.p, y0.data(), sizeof(T) * Npad, hipMemcpyHostToDevice, c->stream));
+        std::vector<T> yr(Npad, (T)0);
+        for (int64_t i = 0; i < N; ++i) yr[i] = yt[i];
+        ALGP_TRY(ensure(c, c->yraw, sizeof(T) * Npad));
+        ALGP_HIP(hipMemcpyAsync(c->yraw.p, yr.data(), sizeof(T) * Npad, hipMemcpyHostToDevice, c->stream));
+        c->train_y_host.assign(N, 0.0);
+        for (int64_t i = 0; i < N; ++i) c->train_y_host[i] = (double)yt[i];
         ALGP_HIP(hipMemcpyAsync(c->varA.p, vv.data(), sizeof(T) * Npad, hipMemcpyHostToDevice, c->stream));
         ALGP_TRY(sync(c));   // host vectors go out of scope
         c->train_var_host.assign(N, 0.0);
@@ -403,8 +409,7 @@ struct Impl {
             }
             // S_RR -= X X^T
             if (frc == ALGP_OK)
-                frc = gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, R, R, Nb, (T)-1, rows, ld, rows, ld, (T)1, rows + Nb, ld,
-                                        rows + Nb, ld, 1);
+                frc = syrk_skinny_sub<T>(c, ALGP_PROF_GEMM_CHOL, rows, R, Nb, ld, rows + Nb, ld, c->auxW);
             double ld_tail = 0;
             if (frc == ALGP_OK)
                 frc = factor_resident(c, rows + Nb, N - Nb, R, p(c->invD) + Nb * NB, SC_LOGDET, SC_INFO, &ld_tail, ld, Nb);
@@ -423,8 +428,33 @@ struct Impl {
         prof_span_end(c);
         ALGP_TRY(frc);
         c->logdet = ld_total;
-        ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
-        ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z)));
+        if (keep > 0) {
+            // z = u - ybar w, u = L^-1 y, w = L^-1 1: the leading entries of u and w only depend on the kept rows of
+            // L (and their y), so the substitutions resume at the first changed block instead of row 0
+            int64_t pu = 0;
+            const int64_t lim = std::min<int64_t>(std::min<int64_t>(p0, c->uw_rows), (int64_t)c->fact_y.size());
+            while (pu < lim && c->fact_y[pu] == c->train_y_host[pu]) ++pu;
+            int64_t ku = std::min<int64_t>(keep, pu / NB * NB);
+            const size_t need = sizeof(T) * (size_t)ld;
+            if (!c->uvec.p || c->uvec.cap < need || !c->wvec.p || c->wvec.cap < need) {
+                ALGP_TRY(ensure(c, c->uvec, need));
+                ALGP_TRY(ensure(c, c->wvec, need));
+                ku = 0;
+            }
+            T* u = p(c->uvec);
+            T* w = p(c->wvec);
+            ALGP_TRY(uw_init_launch<T>(c, u, w, (const T*)c->yraw.p, ku, N, Npad));
+            ALGP_TRY(tail_gemv2_launch<T>(c, p(c->L), ld, ku, Npad, u, w));
+            ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), u, ku / NB));
+            ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), w, ku / NB));
+            ALGP_TRY(uw_combine_launch<T>(c, p(c->z), u, w, (T)c->ybar, Npad));
+            c->uw_rows = N;
+            c->fact_y = c->train_y_host;
+        } else {
+            ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
+            ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z)));
+            c->uw_rows = 0;
+        }
         c->alpha_valid = false;                   // alpha = L^-T z: on first use (need_alpha)
         std::vector<T> zh(Npad);
         ALGP_HIP(hipMemcpyAsync(zh.data(), c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToHost, c->stream));
@@ -656,6 +686,7 @@ struct Impl {
         prof_span_end_on(c, sC);                  // the factorisation proper ends here (on its own stream)
         if (rc == ALGP_OK) {
             hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, sC);
+            c->uw_rows = 0;
             rc = trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z));
         }
         hipEventRecord(sync_event_api(c, EV_Z), sC);
@@ -1311,7 +1342,7 @@ void algp_destroy(algp_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
-                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);

@@ -93,6 +93,11 @@ struct algp_ctx {
     algp::DevBuf Aidx, yA, varA, y0, L, invD, z, alpha, scal;   // scal: device doubles (logdet, info...)
     double ybar = 0, logdet = 0, yalpha = 0;
     bool factored = false;
+    // z = L^-1 (y - ybar 1) = u - ybar w with u = L^-1 y, w = L^-1 1: both are prefix-stable under row appends, so a
+    // factor update only extends them (uw_rows leading rows valid for fact_idx / fact_var / fact_y)
+    algp::DevBuf yraw, uvec, wvec;
+    std::vector<double> train_y_host, fact_y;
+    int64_t uw_rows = 0;
     int64_t factor_rows_from_vt = 0;     // last factor update: rows of L taken from V^T instead of a triangular solve
     bool alpha_valid = false;            // alpha = L^-T z is computed on first use (scoring does not need it)
 
@@ -198,6 +203,16 @@ template <typename T>
 int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
                    int64_t ldd, int lower_only);
+// the same product for `batch` independent problems at element strides sA/sB/sC/sD (grid.y = batch)
+template <typename T>
+int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
+                           int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
+                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch);
+// C (m x m, lower tiles) -= X X^T for a short, very wide X (m <= 512 rows, k columns): the k range is cut into
+// chunks that run as one batched launch, the partial products are summed in chunk order (deterministic)
+template <typename T>
+int syrk_skinny_sub(algp_ctx* c, int klass, const T* X, int64_t m, int64_t k, int64_t ldx, T* C, int64_t ldc,
+                    algp::DevBuf& scratch);
 
 // factor the NB x NB diagonal block at A (ld = lda) in place, write its inverse (NB x NB, ld NB),
 // add sum(log pivot) to *logdet_acc, record first bad pivot (block_row0 + j + 1) in *info (atomicMin style).
@@ -221,7 +236,10 @@ template <typename T>
 int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T* C, int64_t ldc);
 // b <- L^-1 b (forward) and b <- L^-T b (backward) for one vector of length npad
 template <typename T>
-int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b);
+int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b, int64_t kb_start = 0);
+// u[k:] -= L[k:, 0:k] u[0:k] (and the same for w): resume two forward substitutions at row k
+template <typename T>
+int tail_gemv2_launch(algp_ctx* c, const T* L, int64_t ldl, int64_t k, int64_t npad, T* u, T* w);
 template <typename T>
 int trsv_backward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b);
 

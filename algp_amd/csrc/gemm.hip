@@ -44,6 +44,7 @@ struct GemmArgs {
     const T* C;
     T* D;
     int64_t lda, ldb, ldc, ldd;
+    int64_t sA, sB, sC, sD;        // batch strides in elements (blockIdx.y = batch index)
     int tiles_m, tiles_n, ktiles;
     T alpha, beta;
     int lower_only;
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
 
     // ---- staging assignment: chunk id = tid + 256*i -> row = (tid>>3) + 32*i, chunk = tid&7 ----
     const int lrow = tid >> 3, lch = tid & 7;
-    const T* Ag = g.A + (m0 + lrow) * g.lda + lch * EPC;
-    const T* Bg = g.B + (n0 + lrow) * g.ldb + lch * EPC;
+    const int64_t bz = blockIdx.y;
+    const T* Ag = g.A + bz * g.sA + (m0 + lrow) * g.lda + lch * EPC;
+    const T* Bg = g.B + bz * g.sB + (n0 + lrow) * g.ldb + lch * EPC;
     const int woff = lrow * 128 + ((lch ^ ((lrow >> 1) & 7)) << 4);   // (row+32i)>>1 & 7 is i-independent
 
     chunk_t ra[4], rb[4];
@@ -196,6 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
 #endif
     // ---- epilogue: D = alpha*acc + beta*C; all C loads of a 16-row slab are issued before use ----
     const T alpha = g.alpha, beta = g.beta;
+    const T* Cb = g.C + bz * g.sC;
+    T* Db = g.D + bz * g.sD;
     if (beta != (T)0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -204,14 +208,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cv[r][j] = g.C[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
+                for (int j = 0; j < 4; ++j) cv[r][j] = Cb[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
+                    Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
             }
         }
     } else {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
+                for (int j = 0; j < 4; ++j) Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
             }
     }
 }
@@ -275,8 +279,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     // (row>>1)&7 = (4*grp + (l>>4)) & 7 and grp&1 == wave&1 for all four groups.
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-    const T* Ag = g.A + (m0 + 8 * wave + srow) * g.lda + schunk * EPC;
-    const T* Bg = g.B + (n0 + 8 * wave + srow) * g.ldb + schunk * EPC;
+    const int64_t bz = blockIdx.y;
+    const T* Ag = g.A + bz * g.sA + (m0 + 8 * wave + srow) * g.lda + schunk * EPC;
+    const T* Bg = g.B + bz * g.sB + (n0 + 8 * wave + srow) * g.ldb + schunk * EPC;
     auto stage = [&](int st, int kt) {
         char* As = smem + st * 32768 + wave * 1024;
         char* Bs = As + 16384;
@@ -338,6 +343,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     }
 
     const T alpha = g.alpha, beta = g.beta;
+    const T* Cb = g.C + bz * g.sC;
+    T* Db = g.D + bz * g.sD;
     if (beta != (T)0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -346,14 +353,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cv[r][j] = g.C[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
+                for (int j = 0; j < 4; ++j) cv[r][j] = Cb[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
+                    Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
             }
         }
     } else {
@@ -363,22 +370,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g.D[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
+                for (int j = 0; j < 4; ++j) Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
             }
     }
 }
 
 template <typename T>
-int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
-                   int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
-                   int64_t ldd, int lower_only) {
-    if (m <= 0 || n <= 0) return ALGP_OK;
-    if (m % 128 || n % 128 || k % 128 || k <= 0 || lda % 4 || ldb % 4)
+int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
+                           int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
+                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch) {
+    if (m <= 0 || n <= 0 || batch <= 0) return ALGP_OK;
+    if (m % 128 || n % 128 || k % 128 || k <= 0 || lda % 4 || ldb % 4 || sA % 4 || sB % 4)
         return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: operands must be padded to multiples of 128");
     if (lower_only && m != n) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: lower_only needs a square output");
+    if (batch > 65535) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: batch too large");
     GemmArgs<T> g;
-    g.A = A; g.B = B; g.C = C; g.D = D;
+    g.A = A; g.B = B; g.C = C ? C : D; g.D = D;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldd = ldd;
+    g.sA = sA; g.sB = sB; g.sC = sC; g.sD = sD;
     g.tiles_m = (int)(m / 128);
     g.tiles_n = (int)(n / 128);
     g.ktiles = (int)(k / (8 * MF<T>::EPC));
@@ -386,22 +395,37 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
     g.lower_only = lower_only;
     const int64_t tiles = lower_only ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffff) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: grid too large");
-    const double flops = 2.0 * 128.0 * 128.0 * (double)k * (double)tiles;
-    const double bytes = sizeof(T) * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
-                                      (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
+    const double flops = 2.0 * 128.0 * 128.0 * (double)k * (double)tiles * batch;
+    const double bytes = sizeof(T) * batch * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
+                                              (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     ProfScope ps(c, klass, flops, bytes);
-    if (g_gemm_variant == 0) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 0>), dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
-    else if (g_gemm_variant == 2) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 2>), dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
-    else if (g_gemm_variant == 3) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 3>), dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, c->cur, g);
+    const dim3 grid((unsigned)tiles, (unsigned)batch);
+    if (g_gemm_variant == 0) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 0>), grid, dim3(256), 0, c->cur, g);
+    else if (g_gemm_variant == 2) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 2>), grid, dim3(256), 0, c->cur, g);
+    else if (g_gemm_variant == 3) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 3>), grid, dim3(256), 0, c->cur, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
+}
+
+template <typename T>
+int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+                   int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
+                   int64_t ldd, int lower_only) {
+    return gemm_nt_launch_batched<T>(c, klass, m, n, k, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, D, ldd, 0,
+                                     lower_only, 1);
 }
 
 template int gemm_nt_launch<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
                                     const double*, int64_t, double, const double*, int64_t, double*, int64_t, int);
 template int gemm_nt_launch<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
                                    const float*, int64_t, float, const float*, int64_t, float*, int64_t, int);
+template int gemm_nt_launch_batched<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
+                                            int64_t, const double*, int64_t, int64_t, double, const double*, int64_t,
+                                            int64_t, double*, int64_t, int64_t, int, int);
+template int gemm_nt_launch_batched<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
+                                           int64_t, const float*, int64_t, int64_t, float, const float*, int64_t, int64_t,
+                                           float*, int64_t, int64_t, int, int);
 
 // ---------------------------------------------------------------------------------------------
 // MFMA fragment-layout probe (exact integer data, asymmetric B).

@@ -672,6 +672,49 @@ template int trsm_blocked<float>(algp_ctx*, int, float*, int64_t, int64_t, const
                                  const float*, int64_t);
 
 // ---------------------------------------------------------------------------------------------
+// C -= X X^T for a short, very wide X (the R <= 512 new rows of a factor update against N kept columns).
+// One launch with K = N would walk N/16 k-tiles inside 1-10 workgroups (5.3 ms at N = 50 000); instead the
+// K range is cut into chunks, all chunk products run as ONE batched launch into a scratch stack, and a
+// second kernel subtracts them from C in chunk order (fixed order: bitwise reproducible).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void sub_partials_kernel(T* C, int64_t ldc, int64_t m, const T* P, int nchunks) {
+    const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4), j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    if (i >= m || j > i) return;                                   // lower triangle only
+    T s = (T)0;
+    for (int q = 0; q < nchunks; ++q) s += P[(int64_t)q * m * m + i * m + j];
+    C[i * ldc + j] -= s;
+}
+
+template <typename T>
+int syrk_skinny_sub(algp_ctx* c, int klass, const T* X, int64_t m, int64_t k, int64_t ldx, T* C, int64_t ldc,
+                    DevBuf& scratch) {
+    if (m <= 0 || k <= 0) return ALGP_OK;
+    const int64_t kb = k / NB;                                     // 128-column blocks of X
+    int64_t per = (kb + 127) / 128;                                // blocks per chunk: at most 128 chunks ...
+    if (per < 4) per = 4;                                          // ... of at least K = 512
+    const int64_t nfull = kb / per, rem = kb - nfull * per;
+    if (m > 4 * NB || nfull < 2)                                   // not skinny, or nothing to split
+        return gemm_nt_launch<T>(c, klass, m, m, k, (T)-1, X, ldx, X, ldx, (T)1, C, ldc, C, ldc, 1);
+    ALGP_TRY(ensure(c, scratch, sizeof(T) * (size_t)(nfull + 1) * m * m));
+    T* P = (T*)scratch.p;
+    ALGP_TRY(gemm_nt_launch_batched<T>(c, klass, m, m, per * NB, (T)1, X, ldx, per * NB, X, ldx, per * NB, (T)0, nullptr, m,
+                                       m * m, P, m, m * m, 1, (int)nfull));
+    int nch = (int)nfull;
+    if (rem > 0) {
+        ALGP_TRY(gemm_nt_launch<T>(c, klass, m, m, rem * NB, (T)1, X + nfull * per * NB, ldx, X + nfull * per * NB, ldx,
+                                   (T)0, nullptr, m, P + nfull * m * m, m, 1));
+        ++nch;
+    }
+    hipLaunchKernelGGL(sub_partials_kernel<T>, dim3((unsigned)((m + 15) / 16), (unsigned)((m + 15) / 16)), dim3(256), 0,
+                       c->cur, C, ldc, m, P, nch);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int syrk_skinny_sub<double>(algp_ctx*, int, const double*, int64_t, int64_t, int64_t, double*, int64_t, DevBuf&);
+template int syrk_skinny_sub<float>(algp_ctx*, int, const float*, int64_t, int64_t, int64_t, float*, int64_t, DevBuf&);
+
+// ---------------------------------------------------------------------------------------------
 // Vector solves (HBM-bound: each reads the lower triangle of L once).
 //   forward  b <- L^-1 b, right-looking: x_k = inv(L_kk) b_k ; b_{k+1:} -= L_{k+1:,k} x_k
 //   backward b <- L^-T b, right-looking: x_k = inv(L_kk)^T b_k ; b_{0:k} -= L_{k,0:k}^T x_k
@@ -725,11 +768,56 @@ __global__ __launch_bounds__(256) void panel_gemv_t_kernel(const T* R, int64_t l
     out[col] -= s;
 }
 
+// rows [k, k + nrows) of L against the solved leading part: uo[r] -= L[k+r][0:k] . u[0:k] (same for w), one
+// wave per row -- the start-up of a forward substitution that resumes at row k
 template <typename T>
-int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b) {
+__global__ __launch_bounds__(256) void tail_gemv2_kernel(const T* Lrows, int64_t ld, int64_t nrows, int64_t k, const T* u,
+                                                         const T* w, T* uo, T* wo) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const T* row = Lrows + r * ld;
+    T su = (T)0, sw = (T)0;
+    for (int64_t v = lane; v < k / VEC; v += 64) {                 // k is a multiple of 128
+        const vec_t x = *reinterpret_cast<const vec_t*>(row + v * VEC);
+        const vec_t a = *reinterpret_cast<const vec_t*>(u + v * VEC);
+        const vec_t b = *reinterpret_cast<const vec_t*>(w + v * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            su += x[e] * a[e];
+            sw += x[e] * b[e];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        su += __shfl_down(su, o, 64);
+        sw += __shfl_down(sw, o, 64);
+    }
+    if (lane == 0) {
+        uo[r] -= su;
+        wo[r] -= sw;
+    }
+}
+
+template <typename T>
+int tail_gemv2_launch(algp_ctx* c, const T* L, int64_t ldl, int64_t k, int64_t npad, T* u, T* w) {
+    const int64_t nrows = npad - k;
+    if (nrows <= 0 || k <= 0) return ALGP_OK;
+    ProfScope ps(c, ALGP_PROF_TRSV, 4.0 * nrows * k, sizeof(T) * (double)nrows * k);
+    hipLaunchKernelGGL(tail_gemv2_kernel<T>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->cur, L + k * ldl, ldl, nrows,
+                       k, u, w, u + k, w + k);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int tail_gemv2_launch<double>(algp_ctx*, const double*, int64_t, int64_t, int64_t, double*, double*);
+template int tail_gemv2_launch<float>(algp_ctx*, const float*, int64_t, int64_t, int64_t, float*, float*);
+
+template <typename T>
+int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b, int64_t kb_start) {
     const int64_t nblk = npad / NB;
     ProfScope ps(c, ALGP_PROF_TRSV, (double)npad * npad, sizeof(T) * 0.5 * (double)npad * npad);
-    for (int64_t kb = 0; kb < nblk; ++kb) {
+    for (int64_t kb = kb_start; kb < nblk; ++kb) {
         hipLaunchKernelGGL((diag_matvec_kernel<T, false>), dim3(1), dim3(128), 0, c->cur, invD + kb * NB * NB,
                            b + kb * NB);
         const int64_t mrem = npad - (kb + 1) * NB;
@@ -758,8 +846,8 @@ int trsv_backward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* i
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
-template int trsv_forward<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, double*);
-template int trsv_forward<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, float*);
+template int trsv_forward<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, double*, int64_t);
+template int trsv_forward<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, float*, int64_t);
 template int trsv_backward<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, double*);
 template int trsv_backward<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, float*);
 

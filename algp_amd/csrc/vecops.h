@@ -11,6 +11,10 @@ int score_launch(algp_ctx* c, int64_t M, const int* ckind, const unsigned char* 
                  double delta, const double* extra, double* out);
 int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx);
 template <typename T>
+int uw_init_launch(algp_ctx* c, T* u, T* w, const T* y, int64_t k, int64_t n, int64_t npad);
+template <typename T>
+int uw_combine_launch(algp_ctx* c, T* z, const T* u, const T* w, T ybar, int64_t npad);
+template <typename T>
 int gather_rows_launch(algp_ctx* c, const T* src, int64_t lds, const int64_t* src_row, T* dst, int64_t ldd, int64_t nrows,
                        int64_t ncols);
 // lazy greedy refresh (vecops.hip): mode 0 = row pos, 1 = stale rows whose bound reaches scores[pos], 2 = all stale

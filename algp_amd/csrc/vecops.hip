@@ -211,6 +211,37 @@ __device__ __forceinline__ T pick_bprime(bool unit, int64_t pj, const T* Xs, con
     return bp;
 }
 
+// z = u - ybar w ; rhs initialisation for the resumed substitutions: u[i] = y[i], w[i] = (i < n) for i >= k
+template <typename T>
+__global__ void uw_init_kernel(T* u, T* w, const T* y, int64_t k, int64_t n, int64_t npad) {
+    const int64_t i = k + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    u[i] = y[i];
+    w[i] = i < n ? (T)1 : (T)0;
+}
+template <typename T>
+__global__ void uw_combine_kernel(T* z, const T* u, const T* w, T ybar, int64_t npad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) z[i] = u[i] - ybar * w[i];
+}
+template <typename T>
+int uw_init_launch(algp_ctx* c, T* u, T* w, const T* y, int64_t k, int64_t n, int64_t npad) {
+    if (npad <= k) return ALGP_OK;
+    hipLaunchKernelGGL(uw_init_kernel<T>, dim3((unsigned)((npad - k + 255) / 256)), dim3(256), 0, c->cur, u, w, y, k, n, npad);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template <typename T>
+int uw_combine_launch(algp_ctx* c, T* z, const T* u, const T* w, T ybar, int64_t npad) {
+    hipLaunchKernelGGL(uw_combine_kernel<T>, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, c->cur, z, u, w, ybar, npad);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int uw_init_launch<double>(algp_ctx*, double*, double*, const double*, int64_t, int64_t, int64_t);
+template int uw_init_launch<float>(algp_ctx*, float*, float*, const float*, int64_t, int64_t, int64_t);
+template int uw_combine_launch<double>(algp_ctx*, double*, const double*, const double*, double, int64_t);
+template int uw_combine_launch<float>(algp_ctx*, float*, const float*, const float*, float, int64_t);
+
 // dst[r][0:ncols] = src[src_row[r]][0:ncols], or zeros where src_row[r] < 0 (one workgroup per row)
 template <typename T>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* src, int64_t lds, const int64_t* src_row, T* dst,

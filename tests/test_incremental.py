@@ -239,3 +239,54 @@ def test_factor_update_takes_new_rows_from_resident_candidates(dtname):
     assert np.max(np.abs(np.tril(c.factor()) - np.tril(ref.factor()))) < tol
     ref.close()
     c.close()
+
+
+@pytest.mark.parametrize('dtname', ['f64', 'f32'])
+def test_incremental_targets_mean_and_y_only_changes(dtname):
+    """z = L^-1 (y - ybar) is maintained as u - ybar w (u = L^-1 y, w = L^-1 1) and only extended on a factor
+    update: appended sites shift ybar (every entry of z changes), a changed target at an old site restarts the
+    substitution at its block.  alpha, MLL and posterior means must equal a fresh context's."""
+    dt = np.float64 if dtname == 'f64' else np.float32
+    tol = 1e-9 if dtname == 'f64' else 2e-3
+    rng = np.random.RandomState(9)
+    N0, M = 700, 900
+    X = rng.uniform(0, 40, (N0 + M, 2))
+    hyp = (np.log([3.0, 2.0]), 0.0, np.log(1e-2))
+    truth = 5.0 + np.sin(X[:, 0] / 4) + np.cos(X[:, 1] / 5)           # non-zero mean: ybar matters
+    c = _hip.Context(dt)
+    c.set_hypers(*hyp)
+    c.set_pool(X)
+    idx, var = np.arange(N0), rng.choice([0.01, 1.0], N0)
+    y = truth[idx] + 0.1 * rng.standard_normal(N0)
+    test_idx = np.arange(N0 + 600, N0 + M)
+
+    def check():
+        ref = _hip.Context(dt)
+        ref.set_hypers(*hyp)
+        ref.set_pool(X)
+        ref.set_train(idx, y, var)
+        ref.factorize()
+        a1, a2 = c.alpha(), ref.alpha()
+        assert np.max(np.abs(a1 - a2)) < tol * np.max(np.abs(a2))
+        assert abs(c.mll() - ref.mll()) < tol * abs(ref.mll())
+        m1, m2 = c.posterior_mean(test_idx), ref.posterior_mean(test_idx)
+        assert np.max(np.abs(m1 - m2)) < tol * np.max(np.abs(m2))
+        ref.close()
+
+    c.set_train(idx, y, var)
+    c.factorize(incremental=True)
+    check()
+    for step in range(3):                                   # appends (cross a 128 boundary)
+        new = np.arange(N0 + 50 * step, N0 + 50 * step + 50)
+        idx = np.r_[idx, new]
+        var = np.r_[var, rng.choice([0.01, 1.0], 50)]
+        y = np.r_[y, truth[new] + 0.1 * rng.standard_normal(50)]
+        c.set_train(idx, y, var)
+        assert c.factorize(incremental=True) > 0
+        check()
+    y = y.copy()
+    y[300] += 0.7                                           # a re-measured old site: same noise, new fused target
+    c.set_train(idx, y, var)
+    assert c.factorize(incremental=True) == len(idx) // 128 * 128
+    check()
+    c.close()
