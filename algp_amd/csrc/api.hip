@@ -449,11 +449,13 @@ struct Impl {
             ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), w, ku / NB));
             ALGP_TRY(uw_combine_launch<T>(c, p(c->z), u, w, (T)c->ybar, Npad));
             c->uw_rows = N;
+            c->uw_stable = std::min(c->uw_stable, ku);
             c->fact_y = c->train_y_host;
         } else {
             ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
             ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z)));
             c->uw_rows = 0;
+            c->uw_stable = 0;
         }
         c->alpha_valid = false;                   // alpha = L^-T z: on first use (need_alpha)
         std::vector<T> zh(Npad);
@@ -586,7 +588,33 @@ struct Impl {
         ALGP_TRY(trc);
         T* ss = p(c->tvec);
         T* dot = ss + Mpad;
-        ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), M, ldc, Npad, p(c->z), ss, dot));
+        if (incremental && c->uw_rows == N && c->uvec.p && c->wvec.p) {
+            // the factor update maintains z = u - ybar w: carry sum v^2, sum v u, sum v w over the finished column
+            // blocks of V^T from step to step and read only the new columns (a full pass is 40 GB at N = 50 000)
+            const size_t need = sizeof(T) * 6 * (size_t)Mpad;            // 3 running sums + 3 sums of the open tail
+            bool ok = keep > 0 && c->acc3.p && c->acc3.cap >= need && c->acc_M == M && c->acc_cols > 0 &&
+                      c->acc_cols <= keep && c->acc_cols <= c->uw_stable;
+            if (!ok) {
+                ALGP_TRY(ensure(c, c->acc3, need));
+                ALGP_HIP(hipMemsetAsync(c->acc3.p, 0, sizeof(T) * 3 * (size_t)Mpad, c->stream));
+                c->acc_cols = 0;
+            }
+            T* acc = p(c->acc3);
+            T* tmp = acc + 3 * Mpad;
+            for (int64_t j : became_unit)                                 // their kept columns were zeroed above
+                for (int q = 0; q < 3; ++q) ALGP_HIP(hipMemsetAsync(acc + q * Mpad + j, 0, sizeof(T), c->stream));
+            const int64_t fin = N / NB * NB;                              // column blocks no later append can touch
+            if (fin > c->acc_cols)
+                ALGP_TRY(rows_reduce3_launch<T>(c, p(c->Vt), M, ldc, c->acc_cols, fin, p(c->uvec), p(c->wvec), acc, Mpad, 1));
+            ALGP_TRY(rows_reduce3_launch<T>(c, p(c->Vt), M, ldc, fin, Npad, p(c->uvec), p(c->wvec), tmp, Mpad, 0));
+            ALGP_TRY(combine3_launch<T>(c, M, acc, tmp, Mpad, (T)c->ybar, ss, dot));
+            c->acc_cols = fin;
+            c->acc_M = M;
+            c->uw_stable = N;
+        } else {
+            c->acc_cols = 0;
+            ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), M, ldc, Npad, p(c->z), ss, dot));
+        }
         const T prior = (T)(c->hyp.outputscale + (c->prior_noise ? c->hyp.noise : 0.0));
         ALGP_TRY(cand_finalize_launch<T>(c, M, (const int*)c->ckind.p, (const int64_t*)c->Cidx.p,
                                          c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, prior,
@@ -687,6 +715,7 @@ struct Impl {
         if (rc == ALGP_OK) {
             hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, sC);
             c->uw_rows = 0;
+            c->uw_stable = 0;
             rc = trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z));
         }
         hipEventRecord(sync_event_api(c, EV_Z), sC);
@@ -1342,7 +1371,7 @@ void algp_destroy(algp_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
-                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);

@@ -11,6 +11,11 @@ int score_launch(algp_ctx* c, int64_t M, const int* ckind, const unsigned char* 
                  double delta, const double* extra, double* out);
 int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx);
 template <typename T>
+int rows_reduce3_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t c0, int64_t c1, const T* u, const T* w,
+                        T* out3, int64_t stride, int accumulate);
+template <typename T>
+int combine3_launch(algp_ctx* c, int64_t M, const T* acc, const T* tmp, int64_t stride, T ybar, T* ss, T* dot);
+template <typename T>
 int uw_init_launch(algp_ctx* c, T* u, T* w, const T* y, int64_t k, int64_t n, int64_t npad);
 template <typename T>
 int uw_combine_launch(algp_ctx* c, T* z, const T* u, const T* w, T ybar, int64_t npad);

@@ -60,6 +60,86 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const T* Vt, int64_t r
     }
 }
 
+// Column window [c0, c1) (multiples of 128) of every row: sum v^2, sum v u, sum v w; accumulate != 0 adds to the
+// outputs.  Used by the incremental candidate solve: the sums over the kept columns of V^T are carried from
+// step to step and only the new columns are read (the posterior mean needs V.z with z = u - ybar w).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_reduce3_kernel(const T* Vt, int64_t rows, int64_t ldv, int64_t c0, int64_t c1,
+                                                           const T* u, const T* w, T* oss, T* odu, T* odw, int accumulate) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t j = wave; j < rows; j += nw) {
+        const T* row = Vt + j * ldv;
+        T s2 = (T)0, su = (T)0, sw = (T)0;
+        for (int64_t v = c0 / VEC + lane; v < c1 / VEC; v += 64) {
+            const vec_t x = *reinterpret_cast<const vec_t*>(row + v * VEC);
+            const vec_t a = *reinterpret_cast<const vec_t*>(u + v * VEC);
+            const vec_t b = *reinterpret_cast<const vec_t*>(w + v * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                s2 += x[e] * x[e];
+                su += x[e] * a[e];
+                sw += x[e] * b[e];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            s2 += __shfl_down(s2, o, 64);
+            su += __shfl_down(su, o, 64);
+            sw += __shfl_down(sw, o, 64);
+        }
+        if (lane == 0) {
+            if (accumulate) {
+                oss[j] += s2;
+                odu[j] += su;
+                odw[j] += sw;
+            } else {
+                oss[j] = s2;
+                odu[j] = su;
+                odw[j] = sw;
+            }
+        }
+    }
+}
+
+// ss = a_ss + t_ss ; dot = (a_du + t_du) - ybar (a_dw + t_dw)
+template <typename T>
+__global__ void combine3_kernel(int64_t M, const T* acc, const T* tmp, int64_t stride, T ybar, T* ss, T* dot) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    ss[j] = acc[j] + tmp[j];
+    dot[j] = (acc[stride + j] + tmp[stride + j]) - ybar * (acc[2 * stride + j] + tmp[2 * stride + j]);
+}
+
+template <typename T>
+int rows_reduce3_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t c0, int64_t c1, const T* u, const T* w,
+                        T* out3, int64_t stride, int accumulate) {
+    if (rows <= 0) return ALGP_OK;
+    int64_t g = (rows + 3) / 4;
+    if (g > 8192) g = 8192;
+    ProfScope ps(c, ALGP_PROF_ROWS, 6.0 * rows * (double)(c1 - c0), sizeof(T) * (double)rows * (double)(c1 - c0));
+    hipLaunchKernelGGL(rows_reduce3_kernel<T>, dim3((unsigned)g), dim3(256), 0, c->cur, Vt, rows, ldv, c0, c1, u, w, out3,
+                       out3 + stride, out3 + 2 * stride, accumulate);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template <typename T>
+int combine3_launch(algp_ctx* c, int64_t M, const T* acc, const T* tmp, int64_t stride, T ybar, T* ss, T* dot) {
+    if (M <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(combine3_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->cur, M, acc, tmp, stride, ybar,
+                       ss, dot);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int rows_reduce3_launch<double>(algp_ctx*, const double*, int64_t, int64_t, int64_t, int64_t, const double*,
+                                         const double*, double*, int64_t, int);
+template int rows_reduce3_launch<float>(algp_ctx*, const float*, int64_t, int64_t, int64_t, int64_t, const float*, const float*,
+                                        float*, int64_t, int);
+template int combine3_launch<double>(algp_ctx*, int64_t, const double*, const double*, int64_t, double, double*, double*);
+template int combine3_launch<float>(algp_ctx*, int64_t, const float*, const float*, int64_t, float, float*, float*);
+
 template <typename T>
 int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t ncols, const T* w, T* ss,
                        T* dot) {
