@@ -45,6 +45,7 @@ SIGNATURES = {
     'algp_set_train': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p, C.c_void_p]),
     'algp_factorize': (C.c_int, [_c_ctx]),
     'algp_factorize_update': (C.c_int, [_c_ctx, _i64p]),
+    'algp_factorize_from': (C.c_int, [_c_ctx, _c_ctx, _i64p]),
     'algp_fit_and_solve': (C.c_int, [_c_ctx]),
     'algp_get_logdet': (C.c_int, [_c_ctx, _dblp]),
     'algp_get_entropy': (C.c_int, [_c_ctx, _dblp]),
@@ -218,6 +219,13 @@ class Context(object):
             return 0
         kept = C.c_int64()
         self._check(self.lib.algp_factorize_update(self.h, C.byref(kept)))
+        return kept.value
+
+    def factorize_from(self, other):
+        """Adopt the factor `other` holds for the same train set (same device, dtype, hyper-parameters); returns
+        how many leading rows of this context's own factor were kept.  Raises if `other`'s factor does not match."""
+        kept = C.c_int64()
+        self._check(self.lib.algp_factorize_from(self.h, other.h, C.byref(kept)))
         return kept.value
 
     def fit_and_solve(self):

@@ -227,7 +227,24 @@ class Agent(object):
         A = self._train_order(sampled)
         sel = np.array([pos[int(i)] for i in A], dtype=np.int64)
         c.set_train(A, y[sel] if len(sel) else y, var[sel] if len(sel) else var)
-        c.factorize(incremental=True)
+        # The factor of the sampled sites is the one Agent.greedy keeps in the pool context.  When that context is
+        # in step (pool loaded, a candidate solve resident), bring IT up to date first -- the new sites are
+        # resident candidates there, so their rows come from its V^T -- and copy the factor across instead of
+        # solving the new rows against the kept factor a second time.
+        g = self.gp.ctx
+        shared = False
+        if (len(A) and self._pool_key == ('x', id(self.env.X)) and getattr(g, '_pool_owner', None) is self
+                and not self.gp.sync_hypers() and getattr(g, 'M', 0) == n):
+            try:
+                static, mobile = self._masks()
+                g.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
+                g.factorize(incremental=True)
+                c.factorize_from(g)
+                shared = True
+            except (RuntimeError, ValueError):
+                shared = False
+        if not shared:
+            c.factorize(incremental=True)
         test_idx = np.arange(n, n + m)
         if not (return_var or return_cov or return_mi):
             return c.posterior_mean(test_idx)

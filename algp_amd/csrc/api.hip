@@ -427,6 +427,12 @@ struct Impl {
         }
         prof_span_end(c);
         ALGP_TRY(frc);
+        return finish_factor(c, keep, p0, ld_total);
+    }
+
+    // after L (rows >= keep new) is in place: log det, z = L^-1 (y - ybar), y0' S^-1 y0, bookkeeping
+    static int finish_factor(algp_ctx* c, int64_t keep, int64_t p0, double ld_total) {
+        const int64_t N = c->N, Npad = c->Npad, ld = c->Lld;
         c->logdet = ld_total;
         if (keep > 0) {
             // z = u - ybar w, u = L^-1 y, w = L^-1 1: the leading entries of u and w only depend on the kept rows of
@@ -472,6 +478,43 @@ struct Impl {
         c->fact_hyp_stamp = c->hyp_stamp;
         c->kept_rows_last = keep;
         return ALGP_OK;
+    }
+
+    // Take the factor of the same train set from another context of the same device (an agent keeps one context
+    // per candidate set -- the pool for greedy, the held-out points for predict -- and both need the factor of
+    // the sampled sites).  Rows this context already holds for an unchanged leading part are kept; the rest is a
+    // device-to-device copy; z, MLL terms etc. are then computed for THIS context's targets.
+    static int factorize_from(algp_ctx* c, algp_ctx* src) {
+        const int64_t N = c->N, Npad = c->Npad;
+        if (src == c) return fail(c, ALGP_ERR_BAD_ARG, "factorize_from: source and destination are the same context");
+        if (src->dtype != c->dtype || src->device != c->device)
+            return fail(c, ALGP_ERR_BAD_ARG, "factorize_from: contexts differ in dtype or device");
+        if (!src->factored || src->train_dirty) return fail(c, ALGP_ERR_STATE, "factorize_from: the source holds no factor");
+        const Hypers &a = c->hyp, &b = src->hyp;
+        bool same = a.D == b.D && a.kernel == b.kernel && a.outputscale == b.outputscale && a.noise == b.noise;
+        for (int d = 0; same && d < a.D; ++d) same = a.inv_ls[d] == b.inv_ls[d];
+        if (!same) return fail(c, ALGP_ERR_STATE, "factorize_from: hyper-parameters differ");
+        if (src->N != N || src->fact_idx != c->train_idx || src->fact_var != c->train_var_host)
+            return fail(c, ALGP_ERR_STATE, "factorize_from: the source factor belongs to a different train set");
+        int64_t keep = 0, p0 = 0;
+        if (c->factored && c->fact_hyp_stamp == c->hyp_stamp && c->Lld > 0) {
+            const int64_t lim = std::min<int64_t>(N, c->Nfact);
+            while (p0 < lim && c->fact_idx[p0] == c->train_idx[p0] && c->fact_var[p0] == c->train_var_host[p0]) ++p0;
+            keep = p0 / NB * NB;
+        }
+        c->factored = false;
+        c->solved = false;
+        ALGP_TRY(reserve_factor(c, Npad, keep, 0));
+        ALGP_TRY(ensure(c, c->z, sizeof(T) * Npad));
+        ALGP_TRY(ensure(c, c->alpha, sizeof(T) * Npad));
+        hipStreamSynchronize(src->stream);                       // the source's factor is complete
+        if (Npad > keep) {
+            ALGP_HIP(hipMemcpy2DAsync(p(c->L) + keep * c->Lld, sizeof(T) * c->Lld, (const T*)src->L.p + keep * src->Lld,
+                                      sizeof(T) * src->Lld, sizeof(T) * Npad, Npad - keep, hipMemcpyDeviceToDevice, c->stream));
+            ALGP_HIP(hipMemcpyAsync(p(c->invD) + keep * NB, (const T*)src->invD.p + keep * NB, sizeof(T) * (Npad - keep) * NB,
+                                    hipMemcpyDeviceToDevice, c->stream));
+        }
+        return finish_factor(c, keep, p0, src->logdet);
     }
 
     static int need_alpha(algp_ctx* c) {
@@ -1511,6 +1554,18 @@ int algp_set_candidates(algp_ctx* c, const int64_t* idx, int64_t M, int prior_no
     for (int64_t i = 0; i < M; ++i)
         if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "set_candidates: index outside the pool");
     FINISH(c, DISPATCH(c, set_candidates(c, idx, M, prior_noise, extra)));
+}
+int algp_factorize_from(algp_ctx* c, algp_ctx* src, int64_t* kept_rows) {
+    CHECK_CTX(c);
+    if (!src) return fail(c, ALGP_ERR_BAD_ARG, "factorize_from: null source");
+    NEED_HYPERS(c);
+    if (c->n_pool <= 0) return fail(c, ALGP_ERR_STATE, "factorize_from: set a pool first");
+    if (!c->y0.p || (int64_t)c->pos_in_train.size() != c->n_pool)
+        return fail(c, ALGP_ERR_STATE, "factorize_from: call algp_set_train first");
+    int rc = DISPATCH(c, factorize_from(c, src));
+    if (kept_rows) *kept_rows = rc == ALGP_OK ? c->kept_rows_last : 0;
+    if (c->prof_on) prof_collect(c);
+    return rc;
 }
 int algp_fit_and_solve(algp_ctx* c) {
     CHECK_CTX(c);

@@ -105,6 +105,13 @@ int algp_factorize(algp_ctx* ctx);
  * only the rest; appending k sites to N costs O((128+k) N^2).  kept_rows (may be NULL) reports how
  * many rows were reused.  The reference refactorises from scratch at every step (agent.py:210).   */
 int algp_factorize_update(algp_ctx* ctx, int64_t* kept_rows);
+/* Take the factor of the SAME train set (indices, noise, order; same hyper-parameters, dtype and device) from
+ * another context instead of computing it: an agent keeps one context per candidate set (the pool for
+ * Agent.greedy, the held-out points for Agent.predict, agent.py:289-356) and both need chol(C_AA + D).  Rows this
+ * context already holds for an unchanged leading part are kept (*kept_rows), the rest is a device-to-device copy;
+ * z / MLL terms are computed for THIS context's targets.  Both pools must address the train sites by the same
+ * indices.  ALGP_ERR_STATE when the source's factor belongs to another train set or other hyper-parameters.    */
+int algp_factorize_from(algp_ctx* ctx, algp_ctx* src, int64_t* kept_rows);
 /* algp_factorize + algp_solve_candidates as one pipeline: the factorisation runs on a high-priority
  * stream and the candidate solve follows it column block by column block, so the Cholesky's
  * latency-bound panel kernels hide under the solve's GEMMs.  Needs algp_set_train and

@@ -290,3 +290,54 @@ def test_incremental_targets_mean_and_y_only_changes(dtname):
     assert c.factorize(incremental=True) == len(idx) // 128 * 128
     check()
     c.close()
+
+
+def test_factorize_from_another_context():
+    """algp_factorize_from: a second context (other candidates, other targets) adopts the factor of the same
+    train set; a mismatch in train set or hyper-parameters is refused."""
+    rng = np.random.RandomState(12)
+    N, M = 600, 300
+    X = rng.uniform(0, 40, (N + M, 2))
+    hyp = (np.log([3.0, 2.0]), 0.0, np.log(1e-2))
+    idx, var = np.arange(N), rng.choice([0.01, 1.0], N)
+    y = 3.0 + np.sin(X[:N, 0] / 4) + 0.1 * rng.standard_normal(N)
+    a, b, ref = (_hip.Context(np.float64) for _ in range(3))
+    for c in (a, b, ref):
+        c.set_hypers(*hyp)
+        c.set_pool(X)
+    a.set_train(idx, np.zeros(N), var)                      # the greedy-style context: targets are irrelevant there
+    a.factorize()
+    b.set_train(idx, y, var)
+    assert b.factorize_from(a) == 0
+    ref.set_train(idx, y, var)
+    ref.factorize()
+    assert np.array_equal(np.tril(b.factor()), np.tril(ref.factor()))
+    assert b.logdet() == ref.logdet() and np.array_equal(b.alpha(), ref.alpha()) and b.mll() == ref.mll()
+    test_idx = np.arange(N, N + M)
+    for c in (b, ref):
+        c.set_candidates(test_idx, prior_includes_noise=False)
+        c.solve_candidates()
+    assert all(np.array_equal(u, v) for u, v in zip(b.posterior(), ref.posterior()))
+    # grow the train set in the source, adopt again: the leading rows b already has are kept
+    idx2, var2 = np.r_[idx, N + np.arange(40)], np.r_[var, np.full(40, 1.0)]
+    y2 = np.r_[y, 3.0 + 0.1 * rng.standard_normal(40)]
+    a.set_train(idx2, np.zeros(N + 40), var2)
+    a.factorize(incremental=True)
+    b.set_train(idx2, y2, var2)
+    assert b.factorize_from(a) == N // 128 * 128
+    ref.set_train(idx2, y2, var2)
+    ref.factorize()
+    assert np.max(np.abs(np.tril(b.factor()) - np.tril(ref.factor()))) < 1e-11
+    assert np.max(np.abs(b.alpha() - ref.alpha())) < 1e-9 * np.max(np.abs(ref.alpha()))
+    # refusals
+    b.set_train(idx2[:-1], y2[:-1], var2[:-1])
+    with pytest.raises(ValueError):
+        b.factorize_from(a)
+    b.set_train(idx2, y2, var2)
+    b.set_hypers(np.log([3.0, 2.5]), 0.0, np.log(1e-2))
+    with pytest.raises(ValueError):
+        b.factorize_from(a)
+    with pytest.raises(ValueError):
+        a.factorize_from(a)
+    for c in (a, b, ref):
+        c.close()
