@@ -116,3 +116,40 @@ def test_two_contexts_are_independent():
     assert a.device_bytes() > 0
     a.close()
     b.close()
+
+
+def test_greedy_exhausts_candidates_and_free_run_from_empty_field(ctx):
+    """More picks than candidates: the pick-only (lazily resolved) route and the route that returns every
+    utility fail the same way, after the same picks; 40 free-running picks from an empty field follow the oracle."""
+    rng = np.random.RandomState(6)
+    X = rng.uniform(0, 12, (40, 2))
+    ctx.set_hypers(HYP.log_lengthscale, 0.0, HYP.log_noise)
+    ctx.set_pool(X)
+
+    def setup(cand):
+        ctx.set_train(np.arange(30), np.zeros(30), np.full(30, 1.0))
+        ctx.factorize()
+        ctx.set_candidates(cand, prior_includes_noise=True)
+        ctx.solve_candidates()
+
+    cand = np.array([33, 5, 38])                             # two new sites and one mobile-sampled train site
+    setup(cand)
+    full = [int(p) for p in ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3, want_utilities=True)[0]]
+    setup(cand)
+    lazy = [int(p) for p in ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)]
+    assert sorted(full) == [5, 33, 38] and lazy == full
+    for kw in (dict(want_utilities=True), dict()):
+        setup(cand)
+        with pytest.raises(ValueError):
+            ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4, **kw)       # a 4th pick would re-sample a static site
+    # free run from an empty field, picks only
+    Xf = rng.uniform(0, 15, (150, 2))
+    C = O.kernel_matrix(HYP, Xf) + HYP.noise * np.eye(150)
+    none = np.zeros(150, bool)
+    want, _ = O.greedy_fast(C, none, none, 0.1, 1.0, 40, 'entropy')
+    ctx.set_pool(Xf)
+    ctx.set_train(np.zeros(0, np.int64), np.zeros(0))
+    ctx.factorize()
+    ctx.set_candidates(np.arange(150), prior_includes_noise=True)
+    ctx.solve_candidates()
+    assert [int(p) for p in ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 40)] == [int(p) for p in want]
