@@ -101,6 +101,7 @@ struct algp_ctx {
     int64_t uw_stable = 0;               // leading entries of u, w unchanged since the row sums below were started
     // per candidate: sums over the kept columns [0, acc_cols) of V^T of v^2, v u, v w (incremental solve)
     algp::DevBuf acc3;
+    algp::DevBuf splitk;                 // partial products of split-K launches (skinny solves)
     int64_t acc_cols = 0, acc_M = -1;
     int64_t factor_rows_from_vt = 0;     // last factor update: rows of L taken from V^T instead of a triangular solve
     bool alpha_valid = false;            // alpha = L^-T z is computed on first use (scoring does not need it)

@@ -385,6 +385,9 @@ template int trinv_diag_launch<float>(algp_ctx*, const float*, int64_t, float*);
 constexpr int WB = 512;
 
 static hipEvent_t sync_event(algp_ctx* c, size_t i);
+template <typename T>
+int gemm_splitk_sub(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B,
+                    int64_t ldb, T* C, int64_t ldc, DevBuf& scratch);
 
 // factor block column [j0, j0+w) over all rows >= j0, 128 columns at a time (launches go to c->cur)
 template <typename T>
@@ -510,8 +513,8 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
         // block, then update ALL remaining columns with K = 128 -- (npad-k)/128 column tiles in parallel.
         // It re-reads/re-writes the trailing columns each step, which is negligible for so few rows.
         if (col_start > 0)      // columns >= col_start still need the contributions of the kept ones
-            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, npad - col_start, col_start, (T)-1, X, ldx, L + col_start * ldl,
-                                       ldl, (T)1, X + col_start, ldx, X + col_start, ldx, 0));
+            ALGP_TRY(gemm_splitk_sub<T>(c, klass, mpad, npad - col_start, col_start, X, ldx, L + col_start * ldl, ldl,
+                                        X + col_start, ldx, c->splitk));
         for (int64_t k0 = col_start; k0 < npad; k0 += NB) {
             T* Xk = X + k0;
             ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, (T)0,
@@ -677,6 +680,16 @@ template int trsm_blocked<float>(algp_ctx*, int, float*, int64_t, int64_t, const
 // K range is cut into chunks, all chunk products run as ONE batched launch into a scratch stack, and a
 // second kernel subtracts them from C in chunk order (fixed order: bitwise reproducible).
 // ---------------------------------------------------------------------------------------------
+// C (m x n) -= sum over chunks of the partial products P[q] (m x n each, contiguous)
+template <typename T>
+__global__ void sub_partials_rect_kernel(T* C, int64_t ldc, int64_t m, int64_t n, const T* P, int nchunks) {
+    const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4), j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    if (i >= m || j >= n) return;
+    T s = (T)0;
+    for (int q = 0; q < nchunks; ++q) s += P[(int64_t)q * m * n + i * n + j];
+    C[i * ldc + j] -= s;
+}
+
 template <typename T>
 __global__ void sub_partials_kernel(T* C, int64_t ldc, int64_t m, const T* P, int nchunks) {
     const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4), j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
@@ -711,6 +724,37 @@ int syrk_skinny_sub(algp_ctx* c, int klass, const T* X, int64_t m, int64_t k, in
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
+// C (m x n) -= A B^T with few output tiles and a long K (the kept-column contribution to the new columns of a
+// short X): the same split as syrk_skinny_sub -- one batched launch over K chunks, then a fixed-order subtraction.
+// scratch must not alias A, B or C.  Falls back to the plain launch when there is nothing to gain.
+template <typename T>
+int gemm_splitk_sub(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B,
+                    int64_t ldb, T* C, int64_t ldc, DevBuf& scratch) {
+    if (m <= 0 || n <= 0 || k <= 0) return ALGP_OK;
+    const int64_t tiles = (m / NB) * (n / NB), kb = k / NB;
+    int64_t want = tiles > 0 ? 512 / tiles : 1;                    // chunks that would fill the 512 workgroup slots
+    if (want > 128) want = 128;
+    int64_t per = want > 0 ? (kb + want - 1) / want : kb;
+    if (per < 4) per = 4;
+    const int64_t nfull = kb / per, rem = kb - nfull * per;
+    if (tiles > 64 || nfull < 2)
+        return gemm_nt_launch<T>(c, klass, m, n, k, (T)-1, A, lda, B, ldb, (T)1, C, ldc, C, ldc, 0);
+    ALGP_TRY(ensure(c, scratch, sizeof(T) * (size_t)(nfull + 1) * m * n));
+    T* P = (T*)scratch.p;
+    ALGP_TRY(gemm_nt_launch_batched<T>(c, klass, m, n, per * NB, (T)1, A, lda, per * NB, B, ldb, per * NB, (T)0, nullptr, n,
+                                       m * n, P, n, m * n, 0, (int)nfull));
+    int nch = (int)nfull;
+    if (rem > 0) {
+        ALGP_TRY(gemm_nt_launch<T>(c, klass, m, n, rem * NB, (T)1, A + nfull * per * NB, lda, B + nfull * per * NB, ldb,
+                                   (T)0, nullptr, n, P + nfull * m * n, n, 0));
+        ++nch;
+    }
+    hipLaunchKernelGGL(sub_partials_rect_kernel<T>, dim3((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16)), dim3(256), 0,
+                       c->cur, C, ldc, m, n, P, nch);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+
 template int syrk_skinny_sub<double>(algp_ctx*, int, const double*, int64_t, int64_t, int64_t, double*, int64_t, DevBuf&);
 template int syrk_skinny_sub<float>(algp_ctx*, int, const float*, int64_t, int64_t, int64_t, float*, int64_t, DevBuf&);
 

@@ -13,7 +13,7 @@ from algp_amd import _hip
 
 rng = np.random.RandomState(1)
 R0, C0 = (int(v) for v in os.environ.get('LOOP_GRID', '100x100').split('x'))
-N0, M, steps = R0 * C0, 100000, int(os.environ.get('LOOP_STEPS', '6'))
+N0, M, steps = R0 * C0, int(os.environ.get('LOOP_M', '100000')), int(os.environ.get('LOOP_STEPS', '6'))
 xx, yy = np.meshgrid(np.arange(C0), np.arange(R0))
 Xa = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)
 ii, jj = np.meshgrid(np.arange(400), np.arange(250), indexing='ij')
