@@ -45,6 +45,7 @@ SIGNATURES = {
     'algp_set_train': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_void_p, C.c_void_p]),
     'algp_factorize': (C.c_int, [_c_ctx]),
     'algp_factorize_update': (C.c_int, [_c_ctx, _i64p]),
+    'algp_set_constant_mean': (C.c_int, [_c_ctx, C.c_int, C.c_double]),
     'algp_factorize_from': (C.c_int, [_c_ctx, _c_ctx, _i64p]),
     'algp_fit_and_solve': (C.c_int, [_c_ctx]),
     'algp_get_logdet': (C.c_int, [_c_ctx, _dblp]),
@@ -220,6 +221,11 @@ class Context(object):
         kept = C.c_int64()
         self._check(self.lib.algp_factorize_update(self.h, C.byref(kept)))
         return kept.value
+
+    def set_constant_mean(self, value):
+        """Use `value` as the GP's constant mean in the following set_train calls (None: back to the mean of the
+        train targets, models.py:129)."""
+        self._check(self.lib.algp_set_constant_mean(self.h, int(value is not None), 0.0 if value is None else float(value)))
 
     def factorize_from(self, other):
         """Adopt the factor `other` holds for the same train set (same device, dtype, hyper-parameters); returns

@@ -248,11 +248,16 @@ struct Impl {
         c->Npad = Npad;
         c->train_idx.assign(idx, idx + N);
         c->pos_in_train.assign(c->n_pool, -1);
-        for (int64_t i = 0; i < N; ++i) c->pos_in_train[idx[i]] = i;
+        c->train_has_repeats = false;
+        for (int64_t i = 0; i < N; ++i) {                      // a site measured more than once: its FIRST row stands for it
+            if (c->pos_in_train[idx[i]] < 0) c->pos_in_train[idx[i]] = i;
+            else c->train_has_repeats = true;
+        }
         double ybar = 0;
         const T* yt = (const T*)y;
         for (int64_t i = 0; i < N; ++i) ybar += (double)yt[i];
         ybar = N > 0 ? ybar / (double)N : 0.0;
+        if (c->mean_override) ybar = c->mean_value;             // algp_set_constant_mean
         c->ybar = ybar;
         std::vector<T> y0(Npad, (T)0), vv(Npad, (T)0);
         for (int64_t i = 0; i < N; ++i) y0[i] = (T)((double)yt[i] - ybar);
@@ -1026,6 +1031,8 @@ struct Impl {
     // MI criterion extra terms per local candidate: H(A) + H(Abar \ i) - H(all_i)   (agent.py:331-339)
     static int mi_extra(algp_ctx* c, double ss, double sm, std::vector<double>& extra) {
         const int64_t n = c->n_pool, M = c->M;
+        if (c->train_has_repeats)
+            return fail(c, ALGP_ERR_STATE, "mutual_information: the train set lists a site more than once; fuse its readings first");
         const double vf = 1.0 / (1.0 / ss + 1.0 / sm), delta = vf - sm;
         // current state: train set (with its noise) + committed picks
         std::vector<char> sampled(n, 0);
@@ -1493,13 +1500,17 @@ int algp_set_train(algp_ctx* c, const int64_t* idx, int64_t N, const void* y, co
     CHECK_CTX(c);
     if (c->n_pool <= 0) return fail(c, ALGP_ERR_STATE, "set_train: set a pool first");
     if (N < 0 || (N > 0 && (!idx || !y))) return fail(c, ALGP_ERR_BAD_ARG, "set_train: bad arguments");
-    std::vector<char> seen(c->n_pool, 0);
-    for (int64_t i = 0; i < N; ++i) {
+    for (int64_t i = 0; i < N; ++i)
         if (idx[i] < 0 || idx[i] >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "set_train: index outside the pool");
-        if (seen[idx[i]]) return fail(c, ALGP_ERR_BAD_ARG, "set_train: duplicate pool index");
-        seen[idx[i]] = 1;
-    }
     FINISH(c, DISPATCH(c, set_train(c, idx, N, y, var)));
+}
+
+int algp_set_constant_mean(algp_ctx* c, int enable, double value) {
+    CHECK_CTX(c);
+    if (enable && !(value == value)) return fail(c, ALGP_ERR_BAD_ARG, "set_constant_mean: NaN");
+    c->mean_override = enable != 0;
+    c->mean_value = value;
+    return ALGP_OK;
 }
 
 int algp_factorize(algp_ctx* c) {

@@ -90,6 +90,9 @@ struct algp_ctx {
     bool train_dirty = false;
     int64_t kept_rows_last = 0;
     std::vector<int64_t> train_idx;
+    bool mean_override = false;          // algp_set_constant_mean: the GP's constant mean instead of mean(train y)
+    double mean_value = 0;
+    bool train_has_repeats = false;      // a pool index occurs in more than one train row
     algp::DevBuf Aidx, yA, varA, y0, L, invD, z, alpha, scal;   // scal: device doubles (logdet, info...)
     double ybar = 0, logdet = 0, yalpha = 0;
     bool factored = false;

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
                         }
                         if (a.same_pool && pr == pc[v]) {
                             val += a.noise_on_equal;
-                            if (a.diag_add) val += a.diag_add[r];
+                            // the per-row term only on the row's own diagonal entry: two train rows may address the
+                            // same site (independent measurements), and their cross entry is C(i,i) without it
+                            if (a.diag_add && c == r + a.ident_shift) val += a.diag_add[r];
                         }
                     }
                 } else if (a.identity_pad && c == r + a.ident_shift) {

@@ -97,8 +97,17 @@ int algp_set_pool_cov(algp_ctx* ctx, const void* cov, int64_t n);
  * noise (may be NULL = 0).  algp_factorize builds S = C_AA + diag(var) (+ sigma_n^2 I unless the
  * pool is an explicit cov that already has it), factors S = L L^T (blocked, MFMA), solves
  * z = L^-1 (y-ybar), alpha = L^-T z, and accumulates log det S.  Replaces np.linalg.inv at
- * utils.py:300 and slogdet at utils.py:193.                                                    */
+ * utils.py:300 and slogdet at utils.py:193.
+ * A pool index may occur in more than one row: independent measurements of the same site, each
+ * with its own var (cross entries are C(i,i), the site's first row stands for it as a candidate).
+ * Keeping a site's static and mobile means as two rows gives the posterior of the reference's
+ * fused row (agent.py:100-109) with log det S larger by exactly log(ss + sm) per such site, and
+ * turns a re-measurement into an append for algp_factorize_update.  (Not with the MI criterion.)  */
 int algp_set_train(algp_ctx* ctx, const int64_t* idx, int64_t N, const void* y, const void* var);
+/* The GP's constant mean is the mean of the train targets (models.py:129-130).  enable != 0 replaces it by
+ * `value` for the following algp_set_train calls -- needed when the rows are not one per site (a site kept
+ * as two rows must not count twice in the reference's mean of the fused targets).                         */
+int algp_set_constant_mean(algp_ctx* ctx, int enable, double value);
 int algp_factorize(algp_ctx* ctx);
 /* f1: like algp_factorize, but keeps the leading 128-row blocks of the resident
  * factor whose train rows (pool index, noise, order) and hyper-parameters are unchanged and rebuilds

@@ -45,8 +45,7 @@ def test_bad_arguments(ctx):
     ctx.set_pool(np.random.RandomState(0).uniform(0, 5, (20, 2)))
     with pytest.raises(ValueError):
         ctx.set_train([0, 25], [1.0, 2.0])                   # index outside the pool
-    with pytest.raises(ValueError):
-        ctx.set_train([3, 3], [1.0, 2.0])                    # duplicate site
+    ctx.set_train([3, 3], [1.0, 2.0], [0.01, 1.0])           # one site measured twice is legal (two rows)
     with pytest.raises(ValueError):
         ctx.set_candidates([-1])
     with pytest.raises(ValueError):
@@ -153,3 +152,62 @@ def test_greedy_exhausts_candidates_and_free_run_from_empty_field(ctx):
     ctx.set_candidates(np.arange(150), prior_includes_noise=True)
     ctx.solve_candidates()
     assert [int(p) for p in ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 40)] == [int(p) for p in want]
+
+
+@pytest.mark.parametrize('mode', ['coords', 'cov'])
+def test_repeated_measurements_equal_the_fused_row(ctx, mode):
+    """A site with a static and a mobile reading kept as TWO train rows (ss and sm) gives the posterior of the
+    reference's fused row (agent.py:100-109: precision-weighted target, 1/(1/ss+1/sm)); log det S is larger by
+    log(ss+sm) per such site; greedy utilities and picks are the same."""
+    rng = np.random.RandomState(8)
+    n, ss, sm = 260, 0.01, 1.0
+    X = rng.uniform(0, 30, (n, 2))
+    sites = rng.permutation(n)[:120]
+    kind = rng.choice(['s', 'm', 'b'], 120, p=[0.3, 0.4, 0.3])
+    truth = 2.0 + np.sin(X[:, 0] / 4)
+    ys = truth + 0.1 * rng.standard_normal(n)
+    ym = truth + 1.0 * rng.standard_normal(n)
+    vf = 1.0 / (1.0 / ss + 1.0 / sm)
+    fused_y = np.where(kind == 'b', (sm * ys[sites] + ss * ym[sites]) / (ss + sm), np.where(kind == 's', ys[sites], ym[sites]))
+    fused_v = np.where(kind == 'b', vf, np.where(kind == 's', ss, sm))
+    rows_i, rows_y, rows_v = [], [], []
+    for s_, k in zip(sites, kind):                           # first readings in order, the second kind appended at the end
+        rows_i.append(s_)
+        rows_y.append(ys[s_] if k in 'sb' else ym[s_])
+        rows_v.append(ss if k in 'sb' else sm)
+    for s_, k in zip(sites, kind):
+        if k == 'b':
+            rows_i.append(s_)
+            rows_y.append(ym[s_])
+            rows_v.append(sm)
+    ndup = int(np.sum(kind == 'b'))
+    ctx.set_hypers(HYP.log_lengthscale, 0.0, HYP.log_noise)
+    if mode == 'cov':
+        ctx.set_pool_cov(O.kernel_matrix(HYP, X) + HYP.noise * np.eye(n))
+    else:
+        ctx.set_pool(X)
+    static = np.zeros(n, bool)
+    static[sites[kind != 'm']] = True
+    cand = np.arange(n)
+    out = []
+    for idx, y, v in ((sites, fused_y, fused_v), (np.array(rows_i), np.array(rows_y), np.array(rows_v))):
+        ctx.set_constant_mean(float(np.mean(fused_y)) if len(idx) != len(sites) else None)   # the reference's mean
+        ctx.set_train(idx, y, v)
+        ctx.factorize()
+        ld = ctx.logdet()
+        if mode == 'coords':
+            mu = ctx.posterior_mean(cand)
+        ctx.set_candidates(cand, prior_includes_noise=True)
+        ctx.solve_candidates(alive=~static)
+        m2, pv = ctx.posterior()
+        picks, ut = ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 5, want_utilities=True)
+        out.append((ld, m2 if mode == 'cov' else mu, pv, [int(p) for p in picks], ut))
+    (ld1, mu1, pv1, p1, u1), (ld2, mu2, pv2, p2, u2) = out
+    assert abs(ld2 - (ld1 + ndup * np.log(ss + sm))) < 1e-9 * abs(ld1)
+    ordinary = np.ones(n, bool)
+    ordinary[sites] = False                                    # rows of train-site candidates hold [S^-1]_jj instead
+    assert np.max(np.abs(mu1 - mu2)[ordinary]) < 1e-9 and np.max(np.abs(pv1 - pv2)[ordinary]) < 1e-10
+    fin = np.isfinite(u1)
+    assert np.array_equal(fin, np.isfinite(u2)) and np.max(np.abs(u1[fin] - u2[fin])) < 1e-9
+    assert p1 == p2
+    ctx.set_constant_mean(None)
