@@ -21,7 +21,7 @@ import torch
 
 from . import _hip
 from .models import GPR
-from .utils import compute_mae, find_equi_sample_path, find_shortest_path, predictive_distribution
+from .utils import CONST, compute_mae, find_equi_sample_path, find_shortest_path, predictive_distribution
 
 _CRIT = {'entropy': _hip.CRIT_ENTROPY, 'mutual_information': _hip.CRIT_MUTUAL_INFORMATION}
 
@@ -54,6 +54,7 @@ class Agent(object):
         # [env.X; env.test_X] pool -- so each step re-factorises / re-solves only what changed.
         self.incremental = getattr(args, 'incremental', True)
         self._order = []
+        self._rows = []                              # (site, 's' | 'm') in order of the first reading of that kind
         self._pctx = None
         self._pctx_key = None
         self.reset()
@@ -88,6 +89,7 @@ class Agent(object):
         self.static_data = [[] for _ in range(self.env.num_samples)]
         self.mobile_data = [[] for _ in range(self.env.num_samples)]
         self._order = []
+        self._rows = []                              # (site, 's' | 'm') in order of the first reading of that kind
 
     def _pre_train(self, num_samples):
         print('====================================================')
@@ -108,7 +110,10 @@ class Agent(object):
             ys[k] = y
             if not self.static_data[idx] and not self.mobile_data[idx]:
                 self._order.append(int(idx))                 # first reading at this site
-            (self.static_data if sd == self.static_std else self.mobile_data)[idx].append(y)
+            data, kind = (self.static_data, 's') if sd == self.static_std else (self.mobile_data, 'm')
+            if not data[idx]:
+                self._rows.append((int(idx), kind))          # first reading of this kind at this site
+            data[idx].append(y)
         self.collected['ind'] += list(indices)
         self.collected['std'] += list(stds)
         self.collected['y'] += ys
@@ -221,12 +226,25 @@ class Agent(object):
             c.set_pool(np.vstack([np.asarray(self.env.X, np.float64).reshape(n, -1),
                                   np.asarray(self.env.test_X, np.float64).reshape(m, -1)]))
             self._pctx_key = key
-        pos = {int(i): k for k, i in enumerate(ind)}
-        sampled = np.zeros(n, bool)
-        sampled[ind] = True
-        A = self._train_order(sampled)
-        sel = np.array([pos[int(i)] for i in A], dtype=np.int64)
-        c.set_train(A, y[sel] if len(sel) else y, var[sel] if len(sel) else var)
+        rows = self._use_rows()
+        if rows:
+            # one row per (site, kind): targets are the per-kind means, the constant mean is the reference's
+            # (mean of the fused targets, models.py:129 on agent.py:100-109)
+            static, mobile = self._masks()
+            A, is_static = self._train_rows(static, mobile)
+            _, _, ms, mm = self._site_means()
+            ty = np.where(is_static, ms[A], mm[A]) if len(A) else np.zeros(0)
+            tv = self._rows_noise(is_static)
+            c.set_constant_mean(float(np.mean(y)) if len(y) else 0.0)
+            c.set_train(A, ty, tv)
+        else:
+            pos = {int(i): k for k, i in enumerate(ind)}
+            sampled = np.zeros(n, bool)
+            sampled[ind] = True
+            A = self._train_order(sampled)
+            sel = np.array([pos[int(i)] for i in A], dtype=np.int64)
+            c.set_constant_mean(None)
+            c.set_train(A, y[sel] if len(sel) else y, var[sel] if len(sel) else var)
         # The factor of the sampled sites is the one Agent.greedy keeps in the pool context.  When that context is
         # in step (pool loaded, a candidate solve resident), bring IT up to date first -- the new sites are
         # resident candidates there, so their rows come from its V^T -- and copy the factor across instead of
@@ -236,8 +254,11 @@ class Agent(object):
         if (len(A) and self._pool_key == ('x', id(self.env.X)) and getattr(g, '_pool_owner', None) is self
                 and not self.gp.sync_hypers() and getattr(g, 'M', 0) == n):
             try:
-                static, mobile = self._masks()
-                g.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
+                if rows:
+                    g.set_train(A, np.zeros(len(A)), tv)
+                else:
+                    static, mobile = self._masks()
+                    g.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
                 g.factorize(incremental=True)
                 c.factorize_from(g)
                 shared = True
@@ -271,12 +292,65 @@ class Agent(object):
             order += [int(i) for i in np.where(sampled)[0] if i not in seen]
         return np.array(order, dtype=np.int64)
 
+    # ---- one train row per (site, kind of reading) ---------------------------------------------------------
+    # The reference fuses the static and the mobile readings of a site into one row (agent.py:100-109), so a
+    # site that receives the other kind of reading CHANGES an old row (its noise) and an incremental factor has
+    # to be rebuilt from that row on.  Keeping the site's static mean (noise ss) and mobile mean (noise sm) as
+    # two rows is the same GP -- same posterior, log det S larger by log(ss+sm) per such site, the constant mean
+    # taken from the fused targets -- and every new reading becomes an append or a change of a target only.
+    def _use_rows(self):
+        return (getattr(self, 'incremental', False) and getattr(self, 'criterion', 'entropy') == 'entropy'
+                and not self._cov_matrix_user)
+
+    def _train_rows(self, static, mobile, extra_static=(), extra_mobile=()):
+        """(site per row, is_static per row): logged arrival order first, then whatever the masks add."""
+        log = getattr(self, '_rows', [])
+        cache = getattr(self, '_rows_cache', None)
+        if cache is None or cache[0] != len(log) or cache[3] is not log:     # the log only grows: convert the new tail
+            site = np.fromiter((r[0] for r in log), dtype=np.int64, count=len(log))
+            is_s = np.fromiter((r[1] == 's' for r in log), dtype=bool, count=len(log))
+            self._rows_cache = cache = (len(log), site, is_s, log)
+        _, site, is_s, _ = cache
+        n = len(static)
+        ok = np.where(is_s, static[site], mobile[site]) if len(site) else np.zeros(0, bool)
+        site, is_s = site[ok], is_s[ok]
+        has_s = np.zeros(n, bool)
+        has_m = np.zeros(n, bool)
+        has_s[site[is_s]] = True
+        has_m[site[~is_s]] = True
+        parts_i, parts_s = [site], [is_s]
+        for kind_is_s, mask, has, extra in ((True, static, has_s, extra_static), (False, mobile, has_m, extra_mobile)):
+            miss = np.where(mask & ~has)[0]                         # readings not seen by _add_samples (copied data)
+            has[miss] = True
+            ex = np.array([i for i in dict.fromkeys(int(j) for j in extra) if not has[i]], dtype=np.int64)
+            for arr in (miss, ex):
+                parts_i.append(arr.astype(np.int64))
+                parts_s.append(np.full(len(arr), kind_is_s))
+            has[ex] = True
+        # masks first for both kinds, then the extras: keep the documented order (static extras before mobile ones)
+        order = [0, 1, 3, 2, 4]
+        return np.concatenate([parts_i[k] for k in order]), np.concatenate([parts_s[k] for k in order])
+
+    def _rows_noise(self, is_static):
+        return np.where(is_static, self.static_std ** 2, self.mobile_std ** 2)
+
+    def _rows_entropy_offset(self, idx):
+        """H of the row form minus H of the fused form: (CONST + log(ss+sm)/2) per site that has two rows."""
+        n_two = len(idx) - len(np.unique(idx))
+        return n_two * (CONST + 0.5 * np.log(self.static_std ** 2 + self.mobile_std ** 2))
+
     def greedy(self, num_samples):
         """k most informative static sampling sites, greedily (agent.py:295-356)."""
         c = self._load_pool()
         static, mobile = self._masks()
         sampled = static | mobile
-        if getattr(self, 'incremental', False):
+        if self._use_rows():
+            A, is_static = self._train_rows(static, mobile)
+            c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))
+            c.factorize(incremental=True)
+            c.set_candidates(np.arange(self.env.num_samples), prior_includes_noise=True)
+            c.solve_candidates(incremental=True, alive=~static)
+        elif getattr(self, 'incremental', False):
             A = self._train_order(sampled)
             c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
             c.factorize(incremental=True)
@@ -300,6 +374,16 @@ class Agent(object):
         static, mobile0 = self._masks()
         static = static.copy()
         static[static_indices] = True
+        if self._use_rows():
+            # row form: every path only APPENDS rows (a mobile row for each of its sites that has none yet) behind
+            # the common base, even where it re-measures a static site; H is brought back to the fused form
+            utilities = []
+            for path in paths_mobile_indices:
+                A, is_static = self._train_rows(static, mobile0, extra_mobile=[j for j in path if j != -1])
+                c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))
+                c.factorize(incremental=True)
+                utilities.append(c.entropy() - self._rows_entropy_offset(A))
+            return int(np.argmax(utilities))
         base = self._train_order(static | mobile0)          # sites sampled whichever path is taken
         in_base = np.zeros(n, bool)
         in_base[base] = True

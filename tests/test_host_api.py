@@ -279,3 +279,41 @@ def test_best_path_many_paths_vs_oracle_and_reuse(golden):
         a = _agent(g['g4_cov'].astype(np.float64), sd, md, crit)
         idx, ut = O.best_path_ref(g['g4_cov'], g['g4_static'], g['g4_mobile'], paths, si, 0.1, 1.0, crit)
         assert a.best_path(paths, si) == idx
+
+
+def test_agent_row_form_equals_fused_form():
+    """Incremental agents keep one train row per (site, kind of reading) so that a site re-measured by the other
+    sensor appends a row instead of changing an old one; greedy picks, best_path choices and predictions must
+    equal the reference's fused form (agent.py:100-109) -- including sites with both readings and paths that
+    cross static sites."""
+    from algp_amd.agent import Agent
+    from algp_amd.arguments import get_args
+    from algp_amd.field import SyntheticField
+    res = []
+    for inc in (True, False):
+        np.random.seed(11)
+        env = SyntheticField(18, 18, num_test=30)
+        args = get_args(['--eval_only', '--kernel', 'rbf', '--max_iterations', '10', '--fraction_pretrain', '0.25'])
+        args.incremental = inc
+        ag = Agent(env, args)
+        ag._setup_ipp('entropy')
+        rng = np.random.RandomState(4)
+        log = []
+        for step in range(5):
+            picks = ag.greedy(3)
+            ag._add_samples(picks, [ag.static_std] * 3)
+            # mobile readings: new sites, already mobile-sampled sites and STATIC sites (their noise becomes the fused one)
+            static, mobile = ag._masks()
+            pool = np.r_[rng.permutation(env.num_samples)[:6], rng.permutation(np.where(static)[0])[:3],
+                         rng.permutation(np.where(mobile)[0])[:2] if mobile.any() else []].astype(int)
+            ag._add_samples([int(i) for i in pool], [ag.mobile_std] * len(pool))
+            paths = [[int(j) for j in rng.permutation(env.num_samples)[:7]] + [int(np.where(static)[0][k])]
+                     for k in range(4)]
+            choice = ag.best_path(paths, [int(i) for i in rng.permutation(env.num_samples)[:2]])
+            mu, var = ag.predict(return_var=True)
+            log.append((picks, choice, mu.copy(), var.copy()))
+        res.append(log)
+        assert ag._use_rows() == inc
+    for (p1, c1, m1, v1), (p2, c2, m2, v2) in zip(*res):
+        assert p1 == p2 and c1 == c2
+        assert np.max(np.abs(m1 - m2)) < 1e-8 and np.max(np.abs(v1 - v2)) < 1e-9
