@@ -347,7 +347,8 @@ struct Impl {
     // taken from the resident V^T?  Needs V^T solved for the same kept blocks and hyper-parameters, the
     // same candidate list, and every new site an ordinary candidate row.  src_row: V^T row per factor row
     // p0 .. Npad-1 (-1 = padding row, zero).
-    static bool vt_rows_for_new_sites(algp_ctx* c, int64_t Nb, int64_t p0, std::vector<int64_t>& src_row) {
+    static bool vt_rows_for_new_sites(algp_ctx* c, int64_t Nb, int64_t p0, std::vector<int64_t>& src_row,
+                                      std::vector<int64_t>& lrow, std::vector<T>& lscale, bool& any_second) {
         static const bool on = !(getenv("ALGP_FACTOR_FROM_VT") && atoi(getenv("ALGP_FACTOR_FROM_VT")) == 0);
         const int64_t N = c->N, Npad = c->Npad;
         if (!on || !c->Vt.p || c->vt_hyp_stamp != c->hyp_stamp || (int64_t)c->vt_fact_idx.size() < Nb || Nb <= 0) return false;
@@ -355,9 +356,24 @@ struct Impl {
         for (int64_t r = 0; r < Nb; ++r)
             if (c->vt_fact_idx[r] != c->train_idx[r] || c->vt_fact_var[r] != c->train_var_host[r]) return false;
         src_row.assign((size_t)(Npad - p0), -1);
+        lrow.assign((size_t)(Npad - p0), -1);
+        lscale.assign((size_t)(Npad - p0), (T)0);
+        any_second = false;
         for (int64_t i = p0; i < N; ++i) {
-            const int64_t j = c->cand_pos[c->train_idx[i]];
-            if (j < 0 || c->vt_kind[j] != -1) return false;
+            const int64_t q = c->train_idx[i], j = c->cand_pos[q];
+            if (j < 0) return false;
+            const int k = c->vt_kind[j];
+            if (k >= 0) {
+                // a further measurement of a site that already is train row k: its covariances with the old rows
+                // are S[k, :] - var_k e_k^T, so its row is L[k, :] - var_k (e_k^T L^-T), and e_k^T L^-T is the unit
+                // row V^T holds for that candidate
+                if (k >= p0 || c->train_idx[k] != q || (int64_t)c->vt_fact_idx.size() <= k || c->vt_fact_idx[k] != q ||
+                    c->vt_fact_var[k] != c->train_var_host[k])
+                    return false;
+                lrow[(size_t)(i - p0)] = k;
+                lscale[(size_t)(i - p0)] = (T)c->train_var_host[k];
+                any_second = true;
+            }
             src_row[(size_t)(i - p0)] = j;
         }
         return true;
@@ -395,16 +411,27 @@ struct Impl {
             // C[site, A] L^-T against the same kept blocks).  Then rows [Nb, p0) keep what they hold, rows
             // [p0, N) are gathered from V^T and only the R x R tail block of S is regenerated -- no
             // triangular solve against the kept factor (38 ms for 256 rows at N = 50 000).
-            std::vector<int64_t> src_row;
-            if (vt_rows_for_new_sites(c, Nb, p0, src_row)) {
+            std::vector<int64_t> src_row, lrow;
+            std::vector<T> lscale;
+            bool second = false;
+            if (vt_rows_for_new_sites(c, Nb, p0, src_row, lrow, lscale, second)) {
                 frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p + Nb, N - Nb, R, (const int64_t*)c->Aidx.p + Nb, N - Nb, R,
                                      (const T*)c->varA.p + Nb, c->pool_is_cov ? 0 : 1, nullptr, 1, rows + Nb, ld);
-                if (frc == ALGP_OK) frc = ensure(c, c->auxIdx, sizeof(int64_t) * std::max<size_t>(src_row.size(), 1));
-                if (frc == ALGP_OK && !src_row.empty()) {
-                    hipMemcpyAsync(c->auxIdx.p, src_row.data(), sizeof(int64_t) * src_row.size(), hipMemcpyHostToDevice, c->stream);
-                    frc = gather_rows_launch<T>(c, p(c->Vt), c->ldv, (const int64_t*)c->auxIdx.p, p(c->L) + p0 * ld, ld,
-                                                (int64_t)src_row.size(), Nb);
-                    if (frc == ALGP_OK) frc = sync(c);               // src_row is a host temporary
+                const size_t nr = src_row.size();
+                if (frc == ALGP_OK) frc = ensure(c, c->auxIdx, sizeof(int64_t) * 2 * std::max<size_t>(nr, 1));
+                if (frc == ALGP_OK) frc = ensure(c, c->auxVar, sizeof(T) * std::max<size_t>(nr, 1) + 256);
+                if (frc == ALGP_OK && nr > 0) {
+                    int64_t* d_src = (int64_t*)c->auxIdx.p;
+                    int64_t* d_lrow = d_src + nr;
+                    hipMemcpyAsync(d_src, src_row.data(), sizeof(int64_t) * nr, hipMemcpyHostToDevice, c->stream);
+                    if (second) {
+                        hipMemcpyAsync(d_lrow, lrow.data(), sizeof(int64_t) * nr, hipMemcpyHostToDevice, c->stream);
+                        hipMemcpyAsync(c->auxVar.p, lscale.data(), sizeof(T) * nr, hipMemcpyHostToDevice, c->stream);
+                    }
+                    frc = gather_rows_launch<T>(c, p(c->Vt), c->ldv, d_src, p(c->L) + p0 * ld, ld, (int64_t)nr, Nb,
+                                                second ? d_lrow : nullptr, second ? (const T*)c->auxVar.p : nullptr,
+                                                p(c->L), ld);
+                    if (frc == ALGP_OK) frc = sync(c);               // the index vectors are host temporaries
                 }
                 c->factor_rows_from_vt = (int64_t)src_row.size();
             } else {

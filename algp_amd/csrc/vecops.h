@@ -21,7 +21,8 @@ template <typename T>
 int uw_combine_launch(algp_ctx* c, T* z, const T* u, const T* w, T ybar, int64_t npad);
 template <typename T>
 int gather_rows_launch(algp_ctx* c, const T* src, int64_t lds, const int64_t* src_row, T* dst, int64_t ldd, int64_t nrows,
-                       int64_t ncols);
+                       int64_t ncols, const int64_t* lrow = nullptr, const T* lscale = nullptr, const T* Lb = nullptr,
+                       int64_t ldl = 0);
 // lazy greedy refresh (vecops.hip): mode 0 = row pos, 1 = stale rows whose bound reaches scores[pos], 2 = all stale
 template <typename T>
 int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const LazyPick* picks, int npicks, const int* ckind,

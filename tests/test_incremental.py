@@ -201,10 +201,18 @@ def test_factor_update_takes_new_rows_from_resident_candidates(dtname):
     c.set_candidates(cand, prior_includes_noise=True)
     c.solve_candidates(incremental=True)
     c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)                # appended columns / stale rows must not matter
-    for step in range(3):
+    for step in range(4):
         new = np.setdiff1d(cand[rng.permutation(len(cand))[:60]], idx)[:40]
+        nv = rng.choice([0.01, 1.0], len(new))
+        if step >= 1:
+            # second measurements: sites that already are train rows (and unit-row candidates) get another row --
+            # old ones (rows < kept) and one from the previous step's appends
+            again = np.r_[np.arange(N0 - 20, N0 - 20 + 3 * step), idx[-5]]
+            again = np.array([a for a in again if np.sum(idx == a) == 1])
+            new = np.r_[new[:10], again, new[10:]]
+            nv = np.r_[nv[:10], np.full(len(again), 0.01), nv[10:]]
         idx = np.r_[idx, new]
-        var = np.r_[var, rng.choice([0.01, 1.0], len(new))]
+        var = np.r_[var, nv]
         c.set_train(idx, np.zeros(len(idx)), var)
         c.prof_enable(True)
         c.prof_reset()
@@ -221,6 +229,10 @@ def test_factor_update_takes_new_rows_from_resident_candidates(dtname):
         L1, L2 = np.tril(c.factor()), np.tril(ref.factor())
         assert np.max(np.abs(L1 - L2)) < tol * np.max(np.abs(L2))
         assert abs(c.logdet() - ref.logdet()) < tol * abs(ref.logdet())
+        if dtname == 'f64':                                 # and against NumPy on the explicit matrix (repeated sites: the
+            h = O.Hypers(*hyp)                              # cross entry of two rows of one site is C(i,i) = k + sigma_n^2)
+            S = O.kernel_matrix(h, X[idx]) + h.noise * (idx[:, None] == idx[None, :]) + np.diag(var)
+            assert np.max(np.abs(L1 - np.linalg.cholesky(S))) < 1e-11
         ref.close()
         c.set_candidates(cand, prior_includes_noise=True)
         c.solve_candidates(incremental=True)
