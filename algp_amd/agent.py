@@ -117,6 +117,7 @@ class Agent(object):
         self.collected['ind'] += list(indices)
         self.collected['std'] += list(stds)
         self.collected['y'] += ys
+        self._gen = getattr(self, '_gen', 0) + 1                # readings changed (see _masks)
 
     # ---- fusion of repeated readings (agent.py:92-117) --------------------------------------------
     def _site_means(self):
@@ -135,6 +136,7 @@ class Agent(object):
             for i in np.nonzero((cnt != cache['cnt'][k]) | (ids != cache['ids'][k]))[0]:
                 cache['mean'][k][i] = np.mean(data[i]) if cnt[i] else 0.0
             cache['cnt'][k], cache['ids'][k] = cnt, ids
+        cache['gen'] = (getattr(self, '_gen', 0), id(self.static_data), id(self.mobile_data))
         return cache['cnt'][0], cache['cnt'][1], cache['mean'][0], cache['mean'][1]
 
     def get_sampled_dataset(self):
@@ -149,6 +151,10 @@ class Agent(object):
 
     def _masks(self):
         n = self.env.num_samples
+        cache = getattr(self, '_mean_cache', None)
+        if (cache is not None and cache['n'] == n and
+                cache.get('gen') == (getattr(self, '_gen', 0), id(self.static_data), id(self.mobile_data))):
+            return cache['cnt'][0] > 0, cache['cnt'][1] > 0      # nothing was sampled since the last full scan
         static = np.fromiter(map(len, self.static_data), dtype=np.int64, count=n) > 0
         mobile = np.fromiter(map(len, self.mobile_data), dtype=np.int64, count=n) > 0
         return static, mobile
@@ -306,10 +312,14 @@ class Agent(object):
         """(site per row, is_static per row): logged arrival order first, then whatever the masks add."""
         log = getattr(self, '_rows', [])
         cache = getattr(self, '_rows_cache', None)
-        if cache is None or cache[0] != len(log) or cache[3] is not log:     # the log only grows: convert the new tail
-            site = np.fromiter((r[0] for r in log), dtype=np.int64, count=len(log))
-            is_s = np.fromiter((r[1] == 's' for r in log), dtype=bool, count=len(log))
-            self._rows_cache = cache = (len(log), site, is_s, log)
+        if cache is None or cache[3] is not log or cache[0] > len(log):
+            cache = (0, np.zeros(0, np.int64), np.zeros(0, bool), log)
+        if cache[0] != len(log):                                             # the log only grows: convert the new tail
+            tail = log[cache[0]:]
+            site = np.r_[cache[1], np.fromiter((r[0] for r in tail), dtype=np.int64, count=len(tail))]
+            is_s = np.r_[cache[2], np.fromiter((r[1] == 's' for r in tail), dtype=bool, count=len(tail))]
+            cache = (len(log), site, is_s, log)
+        self._rows_cache = cache
         _, site, is_s, _ = cache
         n = len(static)
         ok = np.where(is_s, static[site], mobile[site]) if len(site) else np.zeros(0, bool)
