@@ -10,6 +10,11 @@ void prof_begin(algp_ctx*, int, double, double) {}
 void prof_end(algp_ctx*) {}
 template <typename T>
 int gemm_nt_launch(algp_ctx*, int, int64_t, int64_t, int64_t, T, const T*, int64_t, const T*, int64_t, T, const T*, int64_t, T*, int64_t, int) { return 0; }
+template <typename T>
+int gemm_nt_launch_batched(algp_ctx*, int, int64_t, int64_t, int64_t, T, const T*, int64_t, int64_t, const T*, int64_t, int64_t, T, const T*, int64_t, int64_t, T*, int64_t, int64_t, int, int) { return 0; }
+template int gemm_nt_launch_batched<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t, int64_t, const double*, int64_t, int64_t, double, const double*, int64_t, int64_t, double*, int64_t, int64_t, int, int);
+template int gemm_nt_launch_batched<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t, int64_t, const float*, int64_t, int64_t, float, const float*, int64_t, int64_t, float*, int64_t, int64_t, int, int);
+int ensure(algp_ctx*, DevBuf& b, size_t bytes) { if (b.p) hipFree(b.p); hipMalloc(&b.p, bytes); b.cap = bytes; return 0; }
 template int gemm_nt_launch<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, double, const double*, int64_t, double*, int64_t, int);
 template int gemm_nt_launch<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, float, const float*, int64_t, float*, int64_t, int);
 }
