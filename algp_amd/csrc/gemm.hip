@@ -375,6 +375,145 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 (variant 5, experiment): LDS-DMA staging with FOUR stages of 64-byte rows (4 x 16 KB, still two
+// workgroups per CU) and hand-placed waits, so that the loads of THREE k-tiles (8 f64 / 16 f32 wide each)
+// are in flight while one is multiplied -- the register-staged kernel can only keep one 128-byte k-tile
+// ahead (221 of 256 VGPRs).  Per k-tile and wave: s_waitcnt vmcnt(8) (own DMA of this tile landed, two
+// younger tiles may still fly), s_barrier (everybody's DMA landed, everybody is done reading the stage
+// that is refilled next), 4 global_load_lds for tile kt+3, then 8 ds_read_b128 + 32 MFMAs.
+// LDS image per operand and stage: [128 rows][4 chunks of 16 B], chunk index XOR ((row>>2)&3): a
+// ds_read_b128 of 16 consecutive rows at one chunk index touches 16 distinct 16-byte bank groups.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    using chunk_t = typename F::chunk_t;
+    constexpr int EPC = F::EPC;
+    constexpr int BK = 4 * EPC;                                    // elements per 64-byte row piece
+    constexpr int NST = 4;
+
+    __shared__ __attribute__((aligned(1024))) char smem[NST * 16384];
+
+    const int nwg = gridDim.x;
+    int sid;
+    {
+        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    int bm, bn;
+    if (g.lower_only) {
+        bm = (int)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= sid) ++bm;
+        while ((int64_t)bm * (bm + 1) / 2 > sid) --bm;
+        bn = sid - (int)((int64_t)bm * (bm + 1) / 2);
+    } else {
+        bm = sid / g.tiles_n;
+        bn = sid - bm * g.tiles_n;
+    }
+    const int64_t m0 = (int64_t)bm * 128, n0 = (int64_t)bn * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t bz = blockIdx.y;
+
+    // ---- DMA: wave w stages rows [32w, 32w+32) of each operand as two 16-row groups; lane l -> row l>>2 of
+    // the group, LDS slot l&3, which must hold chunk (l&3) ^ ((row>>2)&3) = (l&3) ^ ((l>>4)&3)
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const T* Ag = g.A + bz * g.sA + (m0 + 32 * wave + srow) * g.lda + schunk * EPC;
+    const T* Bg = g.B + bz * g.sB + (n0 + 32 * wave + srow) * g.ldb + schunk * EPC;
+    auto stage = [&](int st, int kt) {
+        char* As = smem + st * 16384 + wave * 2048;
+        char* Bs = As + 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_vp)(Ag + (int64_t)(16 * i) * g.lda + (int64_t)kt * BK),
+                                             (lds_vp)(As + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(Bg + (int64_t)(16 * i) * g.ldb + (int64_t)kt * BK),
+                                             (lds_vp)(Bs + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment reads: row = w*64 + t*16 + (lane&15), chunk (lane>>4) ^ ((row>>2)&3) ----
+    const int fr = lane & 15, fg = lane >> 4;
+    const int coff = ((fg ^ ((fr >> 2) & 3)) << 4);                // (row>>2)&3 == (fr>>2)&3: the row offsets are multiples of 16
+    const int aoff = (wr * 64 + fr) * 64 + coff;
+    const int boff = (wc * 64 + fr) * 64 + coff;
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+
+    const int nkt = g.ktiles * 2;                                  // g.ktiles counts 128-byte tiles
+    // prologue: tiles 0, 1, 2 in flight
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+    if (nkt > 2) stage(2, 2);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        // own DMA of tile kt has landed when at most the (4 per tile) instructions of the younger tiles remain
+        const int younger = (nkt - 1 - kt) < 2 ? (nkt - 1 - kt) : 2;
+        if (younger == 2) __builtin_amdgcn_s_waitcnt(0x0F78);      // vmcnt(8)
+        else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F74); // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* As = smem + (kt & 3) * 16384;
+        const char* Bs = As + 8192;
+        chunk_t a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 1024);
+        if (kt + 3 < nkt) stage((kt + 3) & 3, kt + 3);             // refills the stage read in iteration kt-1
+        // column by column: the first four MFMAs need a[0..3] and b[0] only, the rest of b lands under them
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+    }
+
+    const T alpha = g.alpha, beta = g.beta;
+    const T* Cb = g.C + bz * g.sC;
+    T* Db = g.D + bz * g.sD;
+    if (beta != (T)0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T cv[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cv[r][j] = Cb[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
+            }
+    }
+}
+
 template <typename T>
 int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
                            int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
@@ -400,9 +539,12 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
                                               (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     ProfScope ps(c, klass, flops, bytes);
     const dim3 grid((unsigned)tiles, (unsigned)batch);
-    if (g_gemm_variant == 0) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 0>), grid, dim3(256), 0, c->cur, g);
-    else if (g_gemm_variant == 2) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 2>), grid, dim3(256), 0, c->cur, g);
-    else if (g_gemm_variant == 3) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 3>), grid, dim3(256), 0, c->cur, g);
+    static const int env_variant = getenv("ALGP_GEMM_VARIANT") ? atoi(getenv("ALGP_GEMM_VARIANT")) : 0;
+    const int variant = g_gemm_variant ? g_gemm_variant : env_variant;
+    if (variant == 0) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 0>), grid, dim3(256), 0, c->cur, g);
+    else if (variant == 2) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 2>), grid, dim3(256), 0, c->cur, g);
+    else if (variant == 3) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 3>), grid, dim3(256), 0, c->cur, g);
+    else if (variant == 5) hipLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, g);
     else hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
