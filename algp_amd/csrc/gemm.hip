@@ -5,21 +5,23 @@
 // All three are "NT" products with both operands contiguous along k, so one staging path serves.
 //
 // Shape: 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each wave 64 x 64 =
-// 4 x 4 MFMA tiles of 16 x 16).  k advances 128 bytes per row per step (16 f64 / 32 f32).
+// 4 x 4 MFMA tiles of 16 x 16).
 //   fp64: v_mfma_f64_16x16x4_f64   (C/D: row = (lane>>4) + 4*reg, col = lane&15)
 //   fp32: v_mfma_f32_16x16x4_f32   (C/D: row = (lane>>4)*4 + reg, col = lane&15)
 // Both take ONE scalar of A and of B per lane (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]).
-// A lane therefore needs, per 16-row fragment, the k-values {g, g+4, g+8, ...} (g = lane>>4).
-// Because the sum over k is order independent we hand lane group g the 16-byte chunk 4q+g of the
-// 128-byte row instead (2 f64 / 4 f32 consecutive k per chunk): one ds_read_b128 then feeds
-// 2 (f64) or 4 (f32) MFMA k-steps, and A and B use the same permutation so products pair up.
+// Because the sum over k is order independent, lane group g = lane>>4 is handed the 16-byte chunk g of the
+// row piece instead (2 f64 / 4 f32 consecutive k per chunk): one ds_read_b128 then feeds 2 (f64) or 4 (f32)
+// MFMA k-steps, and A and B use the same permutation so products pair up.
 //
-// LDS image per operand and stage: [128 rows][8 chunks of 16 B], chunk index XOR ((row>>1)&7).
-//   - staging writes: 8 consecutive lanes write the 8 chunks of one row -> 8 distinct 16-B slots,
-//   - fragment reads (ds_read_b128, 16 rows at one chunk index): (row&1, (row>>1)&7) is distinct
-//     over 16 consecutive rows -> conflict free.
-// Two stages (64 KB) + register prefetch of the next k-tile; one barrier per k-tile; two workgroups
-// per CU (launch bound 2 waves/SIMD) hide each other's barrier and epilogue.
+// Shipped kernel (gemm_nt_kernel_dma4, variant 5): k advances 64 bytes per row per step (8 f64 / 16 f32); the
+// operand pieces go global -> LDS by DMA (global_load_lds_dwordx4, no staging registers, no ds_write pass)
+// into FOUR 16 KB stages, three k-tiles in flight while one is multiplied, with hand-placed
+// s_waitcnt vmcnt(8/4/0) + s_barrier per k-tile; two workgroups per CU (64 KB LDS, 178 VGPRs each).
+// LDS image per operand and stage: [128 rows][4 chunks of 16 B], chunk index XOR ((row>>2)&3).
+// The register-staged kernel it replaced (gemm_nt_kernel_v0, variant 0: 128-byte rows, two 32 KB stages,
+// XOR swizzle ((row>>1)&7), one k-tile of register prefetch, 221 VGPRs) and the two-stage DMA kernel
+// (variant 1) stay selectable for A/B runs: ALGP_GEMM_VARIANT / algp_bench_gemm.
+//   fp64 4096^3: 64.6 (v0) -> 71.0 TFLOP/s (90 % of 78.6); candidate solve in situ 64.8 -> 68.4 TFLOP/s.
 //
 // Requirements (the library pads every matrix to multiples of 128 with zeros / identity):
 //   m % 128 == 0, n % 128 == 0, k % 128 == 0, leading dimensions multiples of 4 elements,
@@ -35,7 +37,8 @@ namespace algp {
 __device__ unsigned long long g_gemm_clk[2 * 8192];
 #endif
 
-int g_gemm_variant = 0;   // 0 = register-staged (default), 1 = LDS-DMA staging (kept for A/B benchmarking)
+int g_gemm_variant = -1;  // -1 = default (5, or ALGP_GEMM_VARIANT); 0 register-staged, 1 two-stage LDS-DMA, 2/3 v0
+                          // experiments, 5 four-stage LDS-DMA (shipped), 6 = 5 + fragment double-buffering
 
 template <typename T>
 struct GemmArgs {
@@ -385,14 +388,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 // LDS image per operand and stage: [128 rows][4 chunks of 16 B], chunk index XOR ((row>>2)&3): a
 // ds_read_b128 of 16 consecutive rows at one chunk index touches 16 distinct 16-byte bank groups.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
+template <typename T, int DB, int NST, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     using chunk_t = typename F::chunk_t;
     constexpr int EPC = F::EPC;
     constexpr int BK = 4 * EPC;                                    // elements per 64-byte row piece
-    constexpr int NST = 4;
 
     __shared__ __attribute__((aligned(1024))) char smem[NST * 16384];
 
@@ -451,34 +453,67 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
     const int nkt = g.ktiles * 2;                                  // g.ktiles counts 128-byte tiles
-    // prologue: tiles 0, 1, 2 in flight
-    stage(0, 0);
-    if (nkt > 1) stage(1, 1);
-    if (nkt > 2) stage(2, 2);
+    // prologue: tiles 0 .. NST-2 in flight
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nkt) stage(t, t);
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        // own DMA of tile kt has landed when at most the (4 per tile) instructions of the younger tiles remain
-        const int younger = (nkt - 1 - kt) < 2 ? (nkt - 1 - kt) : 2;
-        if (younger == 2) __builtin_amdgcn_s_waitcnt(0x0F78);      // vmcnt(8)
-        else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F74); // vmcnt(4)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* As = smem + (kt & 3) * 16384;
+    auto fread = [&](int st, chunk_t (&a)[4], chunk_t (&b)[4]) {
+        const char* As = smem + st * 16384;
         const char* Bs = As + 8192;
-        chunk_t a[4], b[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 1024);
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 1024);
-        if (kt + 3 < nkt) stage((kt + 3) & 3, kt + 3);             // refills the stage read in iteration kt-1
-        // column by column: the first four MFMAs need a[0..3] and b[0] only, the rest of b lands under them
+    };
+    // column by column: the first four MFMAs need a[0..3] and b[0] only, the rest of b lands under them
+    auto fmac = [&](const chunk_t (&a)[4], const chunk_t (&b)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < EPC; ++e)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+    };
+    // wait until this wave's DMA of a tile has landed while `younger` (0..2) later tiles may still fly, then meet
+    auto arrive = [&](int younger) {
+        if (younger >= 3 && NST >= 5) __builtin_amdgcn_s_waitcnt(0x0F7C);       // vmcnt(12)
+        else if (younger >= 2 && NST >= 4) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+        else if (younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F74);              // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    if (DB == 0) {
+        int st = 0;                                                // stage of tile kt; tile kt+NST-1 goes to st-1 (mod NST)
+        for (int kt = 0; kt < nkt; ++kt) {
+            arrive(nkt - 1 - kt);
+            chunk_t a[4], b[4];
+            fread(st, a, b);
+            if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);   // the stage read in iteration kt-1
+            fmac(a, b);
+            st = (st + 1 == NST) ? 0 : st + 1;
+        }
+    } else {
+        // fragments double-buffered: the ds_reads of tile kt+1 fly under the MFMAs of tile kt (tile kt+3 is
+        // issued while tile kt is multiplied and has to land two tiles later)
+        chunk_t a0[4], b0[4], a1[4], b1[4];
+        arrive(nkt - 1);
+        fread(0, a0, b0);
+        for (int kt = 0; kt < nkt; kt += 2) {                      // nkt is even
+            const bool more = kt + 2 < nkt;                        // then kt + 3 < nkt as well
+            arrive(more ? 1 : 0);
+            fread((kt + 1) & 3, a1, b1);
+            if (more) stage((kt + 3) & 3, kt + 3);
+            fmac(a0, b0);
+            if (more) {
+                arrive(1);
+                fread((kt + 2) & 3, a0, b0);
+            }
+            if (kt + 4 < nkt) stage(kt & 3, kt + 4);
+            fmac(a1, b1);
+        }
     }
 
     const T alpha = g.alpha, beta = g.beta;
@@ -539,13 +574,14 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
                                               (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     ProfScope ps(c, klass, flops, bytes);
     const dim3 grid((unsigned)tiles, (unsigned)batch);
-    static const int env_variant = getenv("ALGP_GEMM_VARIANT") ? atoi(getenv("ALGP_GEMM_VARIANT")) : 0;
-    const int variant = g_gemm_variant ? g_gemm_variant : env_variant;
+    static const int default_variant = getenv("ALGP_GEMM_VARIANT") ? atoi(getenv("ALGP_GEMM_VARIANT")) : 5;
+    const int variant = g_gemm_variant >= 0 ? g_gemm_variant : default_variant;
     if (variant == 0) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 0>), grid, dim3(256), 0, c->cur, g);
+    else if (variant == 1) hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(256), 0, c->cur, g);
     else if (variant == 2) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 2>), grid, dim3(256), 0, c->cur, g);
     else if (variant == 3) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 3>), grid, dim3(256), 0, c->cur, g);
-    else if (variant == 5) hipLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(256), 0, c->cur, g);
+    else if (variant == 6) hipLaunchKernelGGL((gemm_nt_kernel_dma4<T, 1, 4, 2>), grid, dim3(256), 0, c->cur, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel_dma4<T, 0, 4, 2>), grid, dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

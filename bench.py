@@ -252,7 +252,7 @@ def main():
                                    % (N, per, args.picks),
                        'n_train': N, 'candidates_per_gpu': per, 'candidates_total': total_c,
                        'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + position)' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel<%s> (candidate TRSM)' % ('double' if args.dtype == 'f64' else 'float'),
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<%s> (candidate TRSM)' % ('double' if args.dtype == 'f64' else 'float'),
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                          'traffic': traffic, 'launches': g['launches'], 'avg_launch_ms': g['ms'] / max(1, g['launches']),
                          'wall_ms_all_launches': span['ms'], 'sum_launch_ms': g['ms'],
