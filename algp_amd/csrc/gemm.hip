@@ -485,6 +485,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel_dma4(GemmArgs<T> g) 
         asm volatile("" ::: "memory");
     };
 
+#ifdef ALGP_GEMM_CLOCK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (DB == 0) {
         int st = 0;                                                // stage of tile kt; tile kt+NST-1 goes to st-1 (mod NST)
         for (int kt = 0; kt < nkt; ++kt) {
@@ -516,6 +519,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel_dma4(GemmArgs<T> g) 
         }
     }
 
+#ifdef ALGP_GEMM_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_gemm_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_gemm_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
     const T alpha = g.alpha, beta = g.beta;
     const T* Cb = g.C + bz * g.sC;
     T* Db = g.D + bz * g.sD;
