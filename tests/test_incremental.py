@@ -1,5 +1,7 @@
 """f1: incremental factor maintenance.  algp_factorize_update must give the same
 factor / alpha / log-det as a from-scratch factorisation while reusing the unchanged leading rows."""
+import os
+
 import numpy as np
 import pytest
 
@@ -220,7 +222,8 @@ def test_factor_update_takes_new_rows_from_resident_candidates(dtname):
         launches = c.prof_get('gemm_chol')['launches']
         c.prof_enable(False)
         assert kept == (len(idx) - len(new)) // 128 * 128
-        assert launches <= 8, launches                      # Schur product + the small tail factorisation only
+        if os.environ.get('ALGP_FACTOR_FROM_VT') != '0':     # (the switch that disables the shortcut, for A/B timing)
+            assert launches <= 8, launches                  # Schur product + the small tail factorisation only
         ref = _hip.Context(dt)
         ref.set_hypers(*hyp)
         ref.set_pool(X)
