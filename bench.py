@@ -257,7 +257,11 @@ def main():
                          'traffic': traffic, 'launches': g['launches'], 'avg_launch_ms': g['ms'] / max(1, g['launches']),
                          'wall_ms_all_launches': span['ms'], 'sum_launch_ms': g['ms'],
                          'note': 'launches of the two row halves overlap on two streams: achieved = flops / wall time of the solves',
-                         'flops_per_launch': g['flops'] / max(1, g['launches'])},
+                         'flops_per_launch': g['flops'] / max(1, g['launches']),
+                         # the same kernel symbol also serves the factorisation: this is the figure rocprofv3 --stats
+                         # reports for the symbol (all its launches), for the cross-check against profiles/
+                         'symbol_launches': g['launches'] + gc['launches'] + gu['launches'],
+                         'symbol_avg_launch_ms': (g['ms'] + gc['ms'] + gu['ms']) / max(1, g['launches'] + gc['launches'] + gu['launches'])},
             'cholesky_tflops': chol_tf, 'cholesky_ms': chol_ms,
             'cholesky_gemm_tflops': (gc['flops'] + gu['flops']) / ((gc['ms'] + gu['ms']) * 1e-3) / 1e12 if gc['ms'] + gu['ms'] > 0 else 0.0,
             # the factorisation's dense rank-512 trailing ("panel") updates on MFMA, HIP-event time of those launches
