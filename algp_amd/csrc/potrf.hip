@@ -12,344 +12,19 @@
 // its explicit 128 x 128 inverse (a GEMM), which keeps all O(n^2 m) work on the matrix cores.
 #include "common.h"
 #include "mfma.h"
+#include "diag.h"
 #include "vecops.h"
 #include <stdlib.h>
 
 namespace algp {
 
-// Diagnostic builds only (tools/potrf_stamp.hip): cycle stamps of thread 0 at phase boundaries.
-#ifdef ALGP_POTRF_STAMPS
-__device__ unsigned long long g_potrf_stamps[64];
-#define ALGP_STAMP(k) do { if (threadIdx.x == 0) g_potrf_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define ALGP_STAMP(k) do { } while (0)
-#endif
-
-// 1/x and 1/sqrt(x) from the hardware seed + Newton steps (a full IEEE fp64 divide / sqrt costs
-// several hundred cycles and sits on the critical path of every pivot column)
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = r * (2.0 - x * r);
-    r = r * (2.0 - x * r);
-    return r;
-}
-__device__ __forceinline__ float fast_rcp(float x) {
-    float r = __builtin_amdgcn_rcpf(x);
-    return r * (2.0f - x * r);
-}
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * (1.5 - 0.5 * x * r * r);
-    r = r * (1.5 - 0.5 * x * r * r);
-    return r;
-}
-__device__ __forceinline__ float fast_rsqrt(float x) {
-    float r = __builtin_amdgcn_rsqf(x);
-    return r * (1.5f - 0.5f * x * r * r);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Diagonal block: factor + invert a 128 x 128 SPD block inside one 256-thread workgroup's LDS.
-//
-// LDS image: only the lower block triangle, as 36 blocks of 16 x 16 with row stride 17
-// (78 KB fp64 / 39 KB fp32): the kernel fits beside one 64 KB GEMM workgroup on a CU, so it can
-// start while a GEMM saturates the chip.  LB(i, j) addresses element (i, j), block(j) <= block(i);
-// inside a diagonal block the strict upper part is free and holds the transposed inverse.
-//   Factor, 16 columns at a time (8 panels):
-//     - panel sweep: thread r owns row k0+r of the panel in registers; the pivot column is gathered
-//       into a double-buffered LDS line (one barrier per column, reciprocal by Newton steps);
-//     - scale the panel: L[i][c] = a[c] / sqrt(d_c);
-//     - rank-16 update of the blocks right of the panel on the matrix cores (4 MFMAs per block).
-//   Inverse X = L^-1 by 16 x 16 blocks: diagonal blocks by per-column substitution, then block row I:
-//     T = sum_K L_IK X_KJ, X_IJ = -X_II T for all J < I on the matrix cores (the accumulator of T is
-//     the B operand of the second product); after a barrier X_IJ overwrites L_IJ, which no later
-//     block row needs.
-// ---------------------------------------------------------------------------------------------
-constexpr int DBS = 16 * 17;                                   // elements per stored block
-__device__ __forceinline__ int LB(int i, int j) {
-    const int I = i >> 4, J = j >> 4;
-    return (I * (I + 1) / 2 + J) * DBS + (i & 15) * 17 + (j & 15);
-}
-
+// The 128 x 128 diagonal block (factor + inverse in one workgroup) lives in diag.h; these kernels only give it
+// a launch of its own.  The dependency-driven Cholesky (chol_dag.hip) calls the same routine as one of its tasks.
 template <typename T, bool FACTOR>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* inv_out, double* logdet_acc,
-                                                          int* info, int64_t block_row0) {
-    __shared__ T S[36 * DBS];
-    __shared__ T dd[128];
-    __shared__ T dinv[128];
-    __shared__ double red[4];
-    __shared__ T prow[2 * 18];
-    __shared__ int bad;
-    using F = MF<T>;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    ALGP_STAMP(0);
-    if (tid == 0) bad = 0;
-    constexpr int VEC = 16 / sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    {
-        // block load over (row, 16-column block) pairs of the lower block triangle: 16-byte global loads,
-        // all of a thread's loads in flight before the first LDS store (a load-per-iteration loop serialises
-        // 64 memory round trips and alone costs >100 us)
-        vec_t tmp[4][16 / VEC];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            // loaded unconditionally (the whole 128 x 128 block is addressable): a load under a runtime
-            // condition makes hipcc branch around it and wait for every load separately
-            const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7;
-#pragma unroll
-            for (int v = 0; v < 16 / VEC; ++v)
-                tmp[u][v] = *reinterpret_cast<const vec_t*>(A + (int64_t)i * lda + 16 * J + v * VEC);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7;
-            if (J <= (i >> 4)) {
-                T* dst = S + LB(i, 16 * J);
-#pragma unroll
-                for (int v = 0; v < 16 / VEC; ++v)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) dst[v * VEC + e] = tmp[u][v][e];
-            }
-        }
-    }
-    __syncthreads();
-    ALGP_STAMP(1);
-
-    if (FACTOR) {
-        for (int k0 = 0; k0 < 128; k0 += 16) {
-            const int k1 = k0 + 16;
-            if (k0 == 0) ALGP_STAMP(2);
-            const int rowid = tid;                       // threads >= 128-k0 idle in the sweep
-            const bool active = rowid < 128 - k0;
-            const int myrow = active ? LB(k0 + rowid, k0) : 0;
-            T a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = active ? S[myrow + c] : (T)0;
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                T* line = prow + (jj & 1) * 18;
-                // column jj of the diagonal 16 x 16 block (lower entries only: the upper triangle is
-                // never kept valid) is gathered from the threads that own those rows
-                if (rowid > jj && rowid < 16) line[rowid] = a[jj];
-                if (rowid == jj) {
-                    const T d = a[jj];
-                    line[16] = fast_rcp(d);
-                    dd[k0 + jj] = d;
-                    if (!(d > (T)0) && bad == 0) bad = k0 + jj + 1;
-                }
-                __syncthreads();
-                if (active && rowid > jj) {
-                    const T ci = a[jj] * line[16];
-#pragma unroll
-                    for (int c = jj + 1; c < 16; ++c) a[c] -= ci * line[c];
-                }
-            }
-            __syncthreads();                             // dd[k0..k1) complete
-            if (tid < 16) dinv[k0 + tid] = fast_rsqrt(dd[k0 + tid]);
-            __syncthreads();
-            if (k0 == 0) ALGP_STAMP(3);
-            if (active) {
-                // branch-free: entries above the diagonal of the 16 x 16 block receive scratch values
-                // (that part of the block is free storage until the inverse phase overwrites it)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const T dv = dinv[k0 + c];
-                    S[myrow + c] = (rowid == c) ? dd[k0 + c] * dv : a[c] * dv;      // sqrt(d) = d / sqrt(d)
-                }
-            }
-            __syncthreads();
-            if (k0 == 0) ALGP_STAMP(4);
-            // ---- rank-16 update of the blocks right of the panel: block (K1+ti, K1+tk) -= P_ti P_tk^T ----
-            const int r = 128 - k1;
-            if (r > 0) {
-                const int K0 = k0 >> 4, K1 = k1 >> 4;
-                const int nb16 = r >> 4, ntile16 = nb16 * (nb16 + 1) / 2;
-                // two tiles per trip: their loads and MFMA chains are independent and overlap
-                for (int t = wave; t < ntile16; t += 8) {
-                    const int t2 = t + 4;
-                    const bool two = t2 < ntile16;
-                    int ti = 0, tj = 0;
-                    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                    const int tk = t - ti * (ti + 1) / 2;
-                    const int tt = two ? t2 : t;
-                    while ((tj + 1) * (tj + 2) / 2 <= tt) ++tj;
-                    const int tl = tt - tj * (tj + 1) / 2;
-                    const int bi = K1 + ti, bk = K1 + tk, ci = K1 + tj, ck = K1 + tl;
-                    const T* Pa = S + (bi * (bi + 1) / 2 + K0) * DBS;
-                    const T* Pb = S + (bk * (bk + 1) / 2 + K0) * DBS;
-                    const T* Qa = S + (ci * (ci + 1) / 2 + K0) * DBS;
-                    const T* Qb = S + (ck * (ck + 1) / 2 + K0) * DBS;
-                    T* Cb = S + (bi * (bi + 1) / 2 + bk) * DBS;
-                    T* Cq = S + (ci * (ci + 1) / 2 + ck) * DBS;
-                    T pa[4], pb[4], qa[4], qb[4];
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        pa[st] = Pa[li * 17 + 4 * st + lg];
-                        pb[st] = Pb[li * 17 + 4 * st + lg];
-                        qa[st] = Qa[li * 17 + 4 * st + lg];
-                        qb[st] = Qb[li * 17 + 4 * st + lg];
-                    }
-                    typename F::acc_t acc, acq;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { acc[q] = (T)0; acq[q] = (T)0; }
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        acc = F::mfma(pa[st], pb[st], acc);
-                        acq = F::mfma(qa[st], qb[st], acq);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Cb[F::row_of(lane, q) * 17 + li] -= acc[q];
-                    if (two) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) Cq[F::row_of(lane, q) * 17 + li] -= acq[q];
-                    }
-                }
-                __syncthreads();
-                if (k0 == 0) ALGP_STAMP(5);
-            }
-        }
-        ALGP_STAMP(6);
-        {
-            double v = (tid < 128) ? log((double)dd[tid]) : 0.0;
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if ((tid & 63) == 0) red[tid >> 6] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            atomicAdd(logdet_acc, red[0] + red[1]);
-            if (bad) atomicCAS(info, 0, (int)(block_row0 + bad));
-        }
-        // write L back, whole 16-element block rows (the strict upper part of the diagonal blocks carries
-        // scratch values: nothing reads it -- see DESIGN.md "data layout")
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7;
-            if (J <= (i >> 4)) {
-                const T* src = S + LB(i, 16 * J);
-#pragma unroll
-                for (int v = 0; v < 16 / VEC; ++v) {
-                    vec_t o;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) o[e] = src[v * VEC + e];
-                    *reinterpret_cast<vec_t*>(A + (int64_t)i * lda + 16 * J + v * VEC) = o;
-                }
-            }
-        }
-    } else {
-        if (tid < 128) dinv[tid] = (T)1 / S[LB(tid, tid)];
-    }
-    __syncthreads();
-    ALGP_STAMP(7);
-
-    // ---- inverse of the diagonal 16 x 16 blocks: one column per thread, values kept in registers;
-    //      X_II[i][c] (i > c) goes to the free upper part of the block, position (c, i) ----
-    if (tid < 128) {
-        const int I = tid >> 4, c = tid & 15, base = I * 16;
-        T* Db = S + (I * (I + 1) / 2 + I) * DBS;
-        // x[k] = 0 for k < c, so the sums run over all k < i with unconditional (broadcast) LDS loads
-        T x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            T sum = (T)0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) sum += Db[i * 17 + k] * x[k];
-            x[i] = (i == c) ? dinv[base + c] : ((i > c) ? -sum * dinv[base + i] : (T)0);
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);          // all reads of the block have landed before its upper part is written
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (i > c) Db[c * 17 + i] = x[i];
-    }
-    __syncthreads();
-    ALGP_STAMP(8);
-    // ---- block rows 1..7 on the matrix cores ----
-    for (int I = 1; I < 8; ++I) {
-        const int r0 = 16 * I;
-        const T* Dii = S + (I * (I + 1) / 2 + I) * DBS;
-        typename F::acc_t outs[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int J = wave + 4 * u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) outs[u][q] = (T)0;
-            if (J < I) {
-                typename F::acc_t acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = (T)0;
-                // K = J: B[k][b] = X_JJ[k][b] = (k > b) ? Djj(b, k) : (k == b ? dinv : 0)
-                {
-                    const T* Lik = S + (I * (I + 1) / 2 + J) * DBS;
-                    const T* Djj = S + (J * (J + 1) / 2 + J) * DBS;
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        const int k = 4 * st + lg;
-                        T bv = (T)0;
-                        if (k > li) bv = Djj[li * 17 + k];
-                        else if (k == li) bv = dinv[16 * J + li];
-                        acc = F::mfma(Lik[li * 17 + k], bv, acc);
-                    }
-                }
-                for (int K = J + 1; K < I; ++K) {
-                    const T* Lik = S + (I * (I + 1) / 2 + K) * DBS;
-                    const T* Xkj = S + (K * (K + 1) / 2 + J) * DBS;          // row-major X_KJ[k][b]
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        const int k = 4 * st + lg;
-                        acc = F::mfma(Lik[li * 17 + k], Xkj[k * 17 + li], acc);
-                    }
-                }
-                // X_IJ = -X_II T: k-step st pairs A[m'][k] with accumulator register st (row k = row_of(lane, st))
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const int k = F::row_of(lane, st);
-                    T av = (T)0;
-                    if (k < li) av = Dii[k * 17 + li];
-                    else if (k == li) av = dinv[r0 + li];
-                    outs[u] = F::mfma(av, acc[st], outs[u]);
-                }
-            }
-        }
-        __syncthreads();                                  // every wave has finished reading L_I*
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int J = wave + 4 * u;
-            if (J < I) {
-                T* Xij = S + (I * (I + 1) / 2 + J) * DBS;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Xij[F::row_of(lane, q) * 17 + li] = -outs[u][q];
-            }
-        }
-        __syncthreads();
-        ALGP_STAMP(9 + I);
-    }
-    // inverse out, 16 elements of a row at a time: left of the diagonal block X_IJ rows, inside it the
-    // transposed upper storage with dinv on the diagonal, zeros to the right
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int pr = tid + 256 * u, i = pr >> 3, J = pr & 7, I = i >> 4, r = i & 15;
-        T row[16];
-        if (J < I) {
-            const T* src = S + LB(i, 16 * J);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) row[e] = src[e];
-        } else if (J == I) {
-            const T* Db = S + (I * (I + 1) / 2 + I) * DBS;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) row[e] = (e < r) ? Db[e * 17 + r] : (e == r ? dinv[i] : (T)0);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) row[e] = (T)0;
-        }
-#pragma unroll
-        for (int v = 0; v < 16 / VEC; ++v) {
-            vec_t o;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = row[v * VEC + e];
-            *reinterpret_cast<vec_t*>(inv_out + i * 128 + 16 * J + v * VEC) = o;
-        }
-    }
-    ALGP_STAMP(17);
+__global__ __launch_bounds__(256) void potrf_diag_kernel(T* A, int64_t lda, T* inv_out, double* logdet_acc, int* info,
+                                                          int64_t block_row0) {
+    __shared__ DiagShared<T> sh;
+    diag128_run<T, FACTOR>(sh, A, lda, inv_out, logdet_acc, true, info, block_row0);
 }
 
 template <typename T>
