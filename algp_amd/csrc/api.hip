@@ -1,6 +1,7 @@
 // api.hip -- extern "C" entry points of libalgp_hip.so (declared in include/algp_hip.h) and the
 // host-side orchestration of the device kernels.  No torch types, no CPU arithmetic fallback:
 // every numeric result comes from the HIP kernels in this directory.
+#include <limits.h>
 #include <math.h>
 #include <string.h>
 
@@ -296,6 +297,8 @@ struct Impl {
         ALGP_TRY(sync(c));
         int info;
         memcpy(&info, &host[1], sizeof(int));
+        if (info == INT_MIN)
+            return fail(c, ALGP_ERR_HIP, "cholesky: the dependency-driven launch stalled (a task's inputs never arrived)");
         if (info != 0) {
             info += (int)pivot_offset;
             c->pivot = info;
@@ -716,171 +719,13 @@ struct Impl {
         return ALGP_OK;
     }
 
-    // GP-fit + candidate solve as ONE pipeline (what a planning step needs, bench.py's step):
-    //   stream C (high priority): S build, blocked Cholesky (an event after every 512-column block), z, alpha
-    //   chunk streams           : B^T rows of the chunk, then the TRSM of the chunk, column block J gated by
-    //                             block J's event; then variance / mean rows once z is there
-    // The factorisation's latency-bound panel kernels (one workgroup each, 80 KB LDS, co-resident with a
-    // GEMM workgroup) hide under the candidate solve's GEMMs instead of idling the chip.
+    // GP-fit + candidate solve of one planning step (bench.py's step): the two phases back to back.  Overlapping the
+    // factorisation with the candidate solve on separate streams was measured in round 1 (207 vs 193 ms/step: the
+    // factorisation's short dependent launches queue behind multi-millisecond GEMM workgroups) and removed; the
+    // factorisation is now a single dependency-driven launch (chol_dag.hip).
     static int fit_and_solve(algp_ctx* c) {
-        const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad;
-        hipStream_t streams[4] = {c->stream, c->stream2, c->stream3, c->stream4};
-        int nch = c->trsm_chunks < 1 ? 1 : (c->trsm_chunks > 4 ? 4 : c->trsm_chunks);
-        const int64_t tiles = Mpad / NB;
-        while (nch > 1 && (!streams[nch - 1] || tiles < 32 * nch)) --nch;
-        // Measured in round 1 (N = 10 000, M = 100 000, fp64): the overlapped pipeline below is SLOWER
-        // than the two phases back to back (207 vs 193 ms/step).  Without preemption each of the
-        // factorisation's ~260 short dependent launches waits up to ~2 ms for a CU slot held by a
-        // multi-millisecond GEMM workgroup of the solve (Cholesky span 19 -> 112 ms), and the solve then
-        // stalls on the per-block events.  It stays selectable (ALGP_PIPELINE=1) for the next round's CU
-        // partitioning experiment; the default is the serial composition.
-        static const bool pipeline = getenv("ALGP_PIPELINE") && atoi(getenv("ALGP_PIPELINE")) != 0;
-        if (!pipeline || !c->streamC || M == 0 || tiles < 64 || nch < 2) {
-            ALGP_TRY(factorize(c, 0));
-            return solve_candidates(c, 0, nullptr);
-        }
-        c->factored = false;
-        c->solved = false;
-        ALGP_TRY(reserve_factor(c, Npad, 0));
-        const int64_t ld = c->Lld, ldv = Npad + MAX_APPEND;
-        ALGP_TRY(ensure(c, c->z, sizeof(T) * Npad));
-        ALGP_TRY(ensure(c, c->alpha, sizeof(T) * Npad));
-        if (!c->Vt.p || c->ldv_cap != ldv || c->Vt.cap < sizeof(T) * Mpad * ldv) {
-            release(c, c->Vt);
-            ALGP_TRY(ensure(c, c->Vt, sizeof(T) * Mpad * ldv));
-            c->ldv_cap = ldv;
-        }
-        c->ldv = ldv;
-        ALGP_TRY(ensure(c, c->dstat, sizeof(T) * Mpad));
-        ALGP_TRY(ensure(c, c->mu, sizeof(T) * Mpad));
-        ALGP_TRY(ensure(c, c->tvec, sizeof(T) * 2 * Mpad));
-        ALGP_TRY(ensure(c, c->alive, Mpad));
-        ALGP_TRY(ensure(c, c->scores, sizeof(double) * Mpad));
-        ALGP_TRY(ensure(c, c->lrow, sizeof(T) * ldv));
-        ALGP_TRY(ensure(c, c->prevrows, sizeof(T) * MAX_APPEND * ldv));
-        std::vector<int> kind(Mpad, -1);
-        if (c->prior_noise)
-            for (int64_t j = 0; j < M; ++j) kind[j] = (int)c->pos_in_train[c->cand_idx[j]];
-        ALGP_TRY(ensure(c, c->ckind, sizeof(int) * Mpad));
-        ALGP_HIP(hipMemcpyAsync(c->ckind.p, kind.data(), sizeof(int) * Mpad, hipMemcpyHostToDevice, c->stream));
-        double* sc = (double*)c->scal.p;
-        ALGP_HIP(hipMemsetAsync(sc + SC_LOGDET, 0, 2 * sizeof(double), c->stream));
-        ALGP_TRY(sync(c));
-
-        struct Flags {
-            algp_ctx* c;
-            int chunks;
-            ~Flags() {
-                c->record_blk_events = c->gate_blk_events = false;
-                c->cur = c->stream;
-                c->trsm_chunks = chunks;
-            }
-        } flags{c, c->trsm_chunks};
-        c->trsm_chunks = 1;                       // the chunking is done here, not inside trsm_blocked
-        KmatSrc s = make_src(c);
-        prof_span_begin(c, ALGP_PROF_CHOLESKY, (double)N * N * N / 3.0, sizeof(T) * (double)N * N);
-        // ---- stream C: S, Cholesky (per-block events), z, alpha ----
-        hipStream_t sC = c->streamC;
-        const size_t EV_START = 4, EV_Z = 5, EV_CDONE = 6, EV_CHUNK = 8;     // sync_event slots (blocks start at 16)
-        ALGP_HIP(hipEventRecord(sync_event_api(c, EV_START), c->stream));
-        ALGP_HIP(hipStreamWaitEvent(sC, sync_event_api(c, EV_START), 0));
-        c->cur = sC;
-        c->record_blk_events = true;
-        int rc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p, N, Npad, (const int64_t*)c->Aidx.p, N, Npad,
-                                (const T*)c->varA.p, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->L), ld);
-        if (rc == ALGP_OK) rc = cholesky_blocked<T>(c, p(c->L), Npad, ld, p(c->invD), sc + SC_LOGDET, (int*)(sc + SC_INFO));
-        c->record_blk_events = false;
-        prof_span_end_on(c, sC);                  // the factorisation proper ends here (on its own stream)
-        if (rc == ALGP_OK) {
-            hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, sC);
-            c->uw_rows = 0;
-            c->uw_stable = 0;
-            rc = trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z));
-        }
-        hipEventRecord(sync_event_api(c, EV_Z), sC);
-        if (rc == ALGP_OK) {
-            hipMemcpyAsync(c->alpha.p, c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, sC);
-            rc = trsv_backward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->alpha));
-        }
-        hipEventRecord(sync_event_api(c, EV_CDONE), sC);
-        // ---- chunk streams: B^T, gated TRSM, row statistics ----
-        T* ss = p(c->tvec);
-        T* dot = ss + Mpad;
-        const T prior = (T)(c->hyp.outputscale + (c->prior_noise ? c->hyp.noise : 0.0));
-        c->gate_blk_events = true;
-        int64_t r0 = 0;
-        for (int k = nch - 1; k >= 0 && rc == ALGP_OK; --k) {
-            const int64_t rows_pad = (k == 0) ? Mpad - r0 : (tiles / nch) * NB;
-            const int64_t rows = std::max<int64_t>(0, std::min<int64_t>(M - r0, rows_pad));
-            hipStream_t st = streams[k];
-            if (k > 0) hipStreamWaitEvent(st, sync_event_api(c, EV_START), 0);
-            c->cur = st;
-            rc = kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p + r0, rows, rows_pad, (const int64_t*)c->Aidx.p, N, ldv,
-                                nullptr, 0, c->prior_noise ? (const int*)c->ckind.p + r0 : nullptr, 0,
-                                p(c->Vt) + r0 * ldv, ldv);
-            if (rc == ALGP_OK && k == nch - 1)
-                prof_span_begin2(c, ALGP_PROF_TRSM, (double)Npad * (double)Npad * (double)Mpad, sizeof(T) * (double)Mpad * Npad);
-            if (rc == ALGP_OK)
-                rc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt) + r0 * ldv, rows_pad, ldv, p(c->L), Npad, ld,
-                                     p(c->invD), 0);
-            hipStreamWaitEvent(st, sync_event_api(c, EV_Z), 0);
-            if (rc == ALGP_OK && rows > 0)
-                rc = rows_reduce_launch<T>(c, p(c->Vt) + r0 * ldv, rows, ldv, Npad, p(c->z), ss + r0, dot + r0);
-            if (rc == ALGP_OK && rows > 0)
-                rc = cand_finalize_launch<T>(c, rows, (const int*)c->ckind.p + r0, (const int64_t*)c->Cidx.p + r0,
-                                             c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, prior,
-                                             c->cextra.p ? (const T*)c->cextra.p + r0 : nullptr, ss + r0, dot + r0,
-                                             (T)c->ybar, p(c->dstat) + r0, p(c->mu) + r0, (unsigned char*)c->alive.p + r0);
-            if (k > 0) {
-                hipEventRecord(sync_event_api(c, EV_CHUNK + (size_t)k), st);
-                hipStreamWaitEvent(c->stream, sync_event_api(c, EV_CHUNK + (size_t)k), 0);
-            }
-            r0 += rows_pad;
-        }
-        c->gate_blk_events = false;
-        c->cur = c->stream;
-        hipStreamWaitEvent(c->stream, sync_event_api(c, EV_CDONE), 0);
-        prof_span_end2(c);
-        // ---- factorisation results (the main stream has joined stream C) ----
-        double host[2];
-        hipMemcpyAsync(host, sc + SC_LOGDET, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        std::vector<T> zh(Npad);
-        hipMemcpyAsync(zh.data(), c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToHost, c->stream);
-        int src = sync(c);
-        ALGP_TRY(rc);
-        ALGP_TRY(src);
-        int info;
-        memcpy(&info, &host[1], sizeof(int));
-        if (info != 0) {
-            c->pivot = info;
-            return fail(c, ALGP_ERR_NOT_PD, "matrix is not positive definite: non-positive pivot at index " +
-                                                std::to_string(info) + " (1-based) of " + std::to_string(N));
-        }
-        c->logdet = host[0];
-        double q = 0;
-        for (int64_t i = 0; i < N; ++i) q += (double)zh[i] * (double)zh[i];
-        c->yalpha = q;
-        c->factored = true;
-        c->alpha_valid = true;
-        c->train_dirty = false;
-        c->Nfact = N;
-        c->fact_idx = c->train_idx;
-        c->fact_var = c->train_var_host;
-        c->fact_hyp_stamp = c->hyp_stamp;
-        c->kept_rows_last = 0;
-        c->ncols = Npad;
-        c->picks.clear();
-        ALGP_TRY(reset_lazy(c));
-        c->solved = true;
-        c->vt_fact_idx = c->fact_idx;
-        c->vt_fact_var = c->fact_var;
-        c->vt_cand_idx = c->cand_idx;
-        c->vt_kind.assign(kind.begin(), kind.begin() + M);
-        c->vt_hyp_stamp = c->hyp_stamp;
-        c->vt_prior_noise = c->prior_noise;
-        c->vt_has_extra = c->cextra.p != nullptr;
-        c->kept_cols_last = 0;
-        return ALGP_OK;
+        ALGP_TRY(factorize(c, 0));
+        return solve_candidates(c, 0, nullptr);
     }
 
     static int get_posterior(algp_ctx* c, void* mu, void* var) {
@@ -1428,14 +1273,6 @@ int algp_create(int device_id, int dtype, algp_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return ALGP_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) c->stream3 = nullptr;
     if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess) c->stream4 = nullptr;
-    {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&c->streamC, hipStreamNonBlocking, hi) != hipSuccess) {
-            (void)hipGetLastError();
-            c->streamC = nullptr;
-        }
-    }
     if (const char* e = getenv("ALGP_TRSM_CHUNKS")) c->trsm_chunks = atoi(e);
     c->cur = c->stream;
     if (ensure(c, c->scal, sizeof(double) * SC_COUNT) != ALGP_OK) { hipStreamDestroy(c->stream); delete c; return ALGP_ERR_OOM; }
@@ -1452,16 +1289,16 @@ void algp_destroy(algp_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
-                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->dag_state, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
+    dag_release(c);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (hipEvent_t e : c->sync_events) hipEventDestroy(e);
     hipStreamSynchronize(c->stream2);
     hipStreamDestroy(c->stream2);
     if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
     if (c->stream4) { hipStreamSynchronize(c->stream4); hipStreamDestroy(c->stream4); }
-    if (c->streamC) { hipStreamSynchronize(c->streamC); hipStreamDestroy(c->streamC); }
     hipStreamDestroy(c->stream);
     delete c;
 }

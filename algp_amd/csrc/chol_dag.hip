@@ -1,0 +1,443 @@
+// chol_dag.hip -- the Cholesky factorisation S = L L^T as ONE dependency-driven launch.
+//
+// Replaces the reference's LU inside np.linalg.inv / np.linalg.slogdet (utils.py:193, 300).  The blocked
+// right-looking factorisation of potrf.hip is a chain of short launches (diagonal block on one workgroup,
+// K = 128 panel launches, one K = 512 update per 512 columns): at N = 10 000 the chip is mostly idle
+// (19.7 TFLOP/s, round 1).  Here the same arithmetic is a list of tile tasks over 128 x 128 tiles
+//     DIAG(k)           L_kk = chol(S_kk), X_kk = inv(L_kk)                  (diag.h, one workgroup)
+//     TRSM(i,k)         L_ik = S_ik X_kk^T                                   (MFMA tile product, K = 128)
+//     UPD(i,j,k0,k1)    S_ij -= L_i,[k0,k1) L_j,[k0,k1)^T                    (MFMA tile product, K = 128 (k1-k0))
+// executed by persistent workgroups that draw tasks from ONE ordered list with an atomic ticket.  A task waits
+// (bounded spin on per-tile version counters) until its inputs are final; because the list is a topological
+// order and tickets are handed out in list order, every task's producers are already held by running
+// workgroups: no deadlock whatever the residency, dispatch order or XCD placement.
+// The order is a list schedule computed on the host (critical-path priorities, simulated on as many workers
+// as the chip holds workgroups), so look-ahead happens by itself: the diagonal chain runs ahead while the
+// K = 512 updates of older block columns fill every other workgroup.
+// Updates of a tile by the W + (0..3) columns just left of it are single K = 128 steps (they sit on or near
+// the critical path); everything older is applied in K = 512 batches (one read + one write of the tile per 512
+// columns keeps the update MFMA-bound instead of HBM-bound).  Each tile receives its updates in ascending k,
+// so the result is bitwise reproducible and independent of the schedule.
+// Hand-off between workgroups (MI355X: per-XCD L2s, per-CU L1s): producer = every wave drains its stores,
+// workgroup barrier, one lane agent-scope release, drain, relaxed agent-scope store of the tile's version;
+// consumer = one wave polls (relaxed agent-scope loads), one agent-scope acquire, drain, barrier, plain loads.
+#include "common.h"
+#include "mfma.h"
+#include "diag.h"
+#include <algorithm>
+#include <queue>
+#include <stdlib.h>
+
+namespace algp {
+
+enum { DAG_DIAG = 0, DAG_TRSM = 1, DAG_UPD = 2 };
+struct DagTask {
+    int type, i, j, kk;                                        // kk = (k0 << 16) | k1
+};
+
+template <typename T>
+struct DagArgs {
+    T* L;
+    int64_t ld;
+    T* invD;
+    const DagTask* tasks;
+    int ntasks, nt;
+    int* ver;                                                  // nt x nt tile versions (number of column steps applied)
+    int* ctrl;                                                 // [0] ticket, [1] abort code, [2] spins (diagnostic)
+    double* ld_blocks;                                         // per diagonal block: sum(log pivots)
+    int* info;
+};
+
+// Diagnostic builds only (tools/dag_test.hip): per-workgroup progress words the host can read while the launch runs.
+#ifdef ALGP_DAG_DEBUG
+__device__ int g_dag_dbg[4 * 1024];
+#define DAG_DBG(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 1024) __hip_atomic_store(&g_dag_dbg[4 * blockIdx.x + (slot)], (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define DAG_DBG(slot, val) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+// ---- 128 x 128 tile product acc += A B^T, A and B row-major with k contiguous: the four-stage LDS-DMA
+// pipeline of gemm.hip (three 64-byte k-tiles in flight while one is multiplied) as a device routine ----
+template <typename T>
+__device__ __forceinline__ void tile_mainloop(char* smem, const T* A0, int64_t lda, const T* B0, int64_t ldb, int nkt,
+                                              typename MF<T>::acc_t (&acc)[4][4]) {
+    using F = MF<T>;
+    using chunk_t = typename F::chunk_t;
+    constexpr int EPC = F::EPC;
+    constexpr int BK = 4 * EPC;
+    constexpr int NST = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const T* Ag = A0 + (int64_t)(32 * wave + srow) * lda + schunk * EPC;
+    const T* Bg = B0 + (int64_t)(32 * wave + srow) * ldb + schunk * EPC;
+    auto stage = [&](int st, int kt) {
+        char* As = smem + st * 16384 + wave * 2048;
+        char* Bs = As + 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_vp)(Ag + (int64_t)(16 * i) * lda + (int64_t)kt * BK),
+                                             (lds_vp)(As + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(Bg + (int64_t)(16 * i) * ldb + (int64_t)kt * BK),
+                                             (lds_vp)(Bs + i * 1024), 16, 0, 0);
+        }
+    };
+    const int fr = lane & 15, fg = lane >> 4;
+    const int coff = ((fg ^ ((fr >> 2) & 3)) << 4);
+    const int aoff = (wr * 64 + fr) * 64 + coff;
+    const int boff = (wc * 64 + fr) * 64 + coff;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nkt) stage(t, t);
+    auto fread = [&](int st, chunk_t (&a)[4], chunk_t (&b)[4]) {
+        const char* As = smem + st * 16384;
+        const char* Bs = As + 8192;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 1024);
+    };
+    auto fmac = [&](const chunk_t (&a)[4], const chunk_t (&b)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+    };
+    auto arrive = [&](int younger) {
+        if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);       // vmcnt(8)
+        else if (younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int st = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        arrive(nkt - 1 - kt);
+        chunk_t a[4], b[4];
+        fread(st, a, b);
+        if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);
+        fmac(a, b);
+        st = (st + 1 == NST) ? 0 : st + 1;
+    }
+}
+
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    __shared__ __attribute__((aligned(1024))) union {
+        DiagShared<T> diag;
+        char gemm[4 * 16384];
+    } sm;
+    __shared__ int s_ticket, s_ok;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15;
+    const int nt = g.nt;
+
+    for (;;) {
+        if (tid == 0) s_ticket = atomicAdd(&g.ctrl[0], 1);
+        __syncthreads();                                       // also: every wave is done with the previous task's LDS
+        // wave-uniform in fact, and told so to the compiler: with a (formally) divergent loop exit hipcc lets the
+        // lanes that stay in the loop run ahead into the next iteration's barrier before lane 0 has published
+        const int t = __builtin_amdgcn_readfirstlane(s_ticket);
+        DAG_DBG(0, t);
+        DAG_DBG(1, 1);
+        if (t >= g.ntasks) break;
+        const DagTask task = g.tasks[t];
+        const int type = task.type, ti = task.i, tj = task.j, k0 = task.kk >> 16, k1 = task.kk & 0xffff;
+
+        // ---- wait for the inputs: lane l of wave 0 polls dependency l ----
+        if (wave == 0) {
+            int ndeps, di = ti, dj = tj, want = 0;
+            if (type == DAG_DIAG) {
+                ndeps = 1; want = ti;                          // tile (k,k) has received its k updates
+            } else if (type == DAG_TRSM) {
+                ndeps = 2;
+                if (lane == 0) want = tj;                      // tile (i,k) updated k times
+                else { di = tj; dj = tj; want = tj + 1; }      // diagonal block k factored
+            } else {
+                const int n = k1 - k0;
+                ndeps = 1 + (ti == tj ? n : 2 * n);
+                if (lane == 0) want = k0;
+                else if (lane <= n) { dj = k0 + lane - 1; want = dj + 1; }
+                else { di = tj; dj = k0 + lane - n - 1; want = dj + 1; }
+            }
+            const bool mine = lane < ndeps;
+            int* addr = g.ver + (mine ? (int64_t)di * nt + dj : 0);
+            bool ok = false;
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spins = 0;; ++spins) {
+                const int v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = __all(!mine || v >= want);
+                if (ok) break;
+                if (__hip_atomic_load(&g.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t_start > 200000000ull) {   // 2 s at 100 MHz
+                    if (lane == 0) atomicCAS(&g.ctrl[1], 0, t + 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (ok) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (lane == 0) s_ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!__builtin_amdgcn_readfirstlane(s_ok)) break;
+        DAG_DBG(1, 2);
+
+        if (type == DAG_DIAG) {
+            const int k = ti;
+            T* Akk = g.L + (int64_t)k * 128 * g.ld + (int64_t)k * 128;
+            diag128_factor<T>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, g.ld_blocks + k, false, g.info,
+                              (int64_t)k * 128);
+        } else {
+            T* Cij = g.L + (int64_t)ti * 128 * g.ld + (int64_t)tj * 128;
+            acc_t acc[4][4];
+            const T* A0;
+            const T* B0;
+            int64_t ldb;
+            int nkt;
+            if (type == DAG_UPD) {
+                // acc = -C, then acc += A B^T, then C = -acc
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j][r] = -Cij[gi * g.ld + wc * 64 + j * 16 + fr];
+                    }
+                A0 = g.L + (int64_t)ti * 128 * g.ld + (int64_t)k0 * 128;
+                B0 = g.L + (int64_t)tj * 128 * g.ld + (int64_t)k0 * 128;
+                ldb = g.ld;
+                nkt = (k1 - k0) * (128 / (4 * F::EPC));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+                A0 = Cij;                                      // in place: every read of the tile precedes the stores
+                B0 = g.invD + (int64_t)tj * 128 * 128;
+                ldb = 128;
+                nkt = 128 / (4 * F::EPC);
+            }
+            tile_mainloop<T>(sm.gemm, A0, g.ld, B0, ldb, nkt, acc);
+            const T sgn = (type == DAG_UPD) ? (T)-1 : (T)1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Cij[gi * g.ld + wc * 64 + j * 16 + fr] = sgn * acc[i][j][r];
+                }
+        }
+        // ---- publish: all stores drained, barrier, one release, drain, version store ----
+        DAG_DBG(1, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave == 0) {                                       // a wave-uniform branch (see the note at the ticket)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int newver = (type == DAG_UPD) ? k1 : tj + 1;
+            if (lane == 0)
+                __hip_atomic_store(g.ver + (int64_t)ti * nt + tj, newver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        DAG_DBG(1, 4);
+    }
+    DAG_DBG(1, 5);
+}
+
+// sum of the per-block log-determinants in block order (deterministic), abort code -> info
+__global__ void dag_finish_kernel(const double* ld_blocks, int nt, const int* ctrl, double* logdet_acc, int* info) {
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int k = 0; k < nt; ++k) s += ld_blocks[k];
+        *logdet_acc += s;
+        if (ctrl[1] != 0) *info = -2147483647 - 1;             // stalled: reported as a HIP-level failure by the caller
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side: the task list in list-schedule order.
+// ---------------------------------------------------------------------------------------------
+struct DagSchedule {
+    int64_t nt = 0;
+    int window = 0;
+    std::vector<DagTask> tasks;
+};
+
+static int batched_until(int j, int W) {                       // columns [0, kf) of tile column j arrive in batches of 4
+    if (j < W) return 0;
+    return 4 * ((j - W) / 4);
+}
+
+void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
+    struct Node {
+        DagTask t;
+        float dur, prio;
+        int npred;
+        std::vector<int> succ;
+    };
+    std::vector<Node> nodes;
+    std::vector<int> last_writer((size_t)nt * nt, -1), trsm((size_t)nt * nt, -1), diag(nt, -1);
+    auto add = [&](int type, int i, int j, int k0, int k1, float dur) {
+        Node n;
+        n.t = DagTask{type, i, j, (k0 << 16) | k1};
+        n.dur = dur;
+        n.prio = 0;
+        n.npred = 0;
+        nodes.push_back(std::move(n));
+        return (int)nodes.size() - 1;
+    };
+    auto edge = [&](int from, int to) {
+        if (from < 0) return;
+        nodes[from].succ.push_back(to);
+        nodes[to].npred++;
+    };
+    // durations in microseconds (two workgroups share a CU's matrix cores): only their proportions matter
+    const float D_DIAG = 55.f, D_OP = 28.f, D_OVH = 9.f;
+    for (int k = 0; k < nt; ++k) {
+        const int d = add(DAG_DIAG, k, k, k, k + 1, D_DIAG);
+        edge(last_writer[(size_t)k * nt + k], d);
+        diag[k] = d;
+        for (int i = k + 1; i < nt; ++i) {
+            const int tr = add(DAG_TRSM, i, k, k, k + 1, D_OP + D_OVH);
+            edge(d, tr);
+            edge(last_writer[(size_t)i * nt + k], tr);
+            trsm[(size_t)i * nt + k] = tr;
+        }
+        auto upd = [&](int i, int j, int k0, int k1) {
+            const int u = add(DAG_UPD, i, j, k0, k1, D_OVH + D_OP * (k1 - k0));
+            edge(last_writer[(size_t)i * nt + j], u);
+            for (int kk = k0; kk < k1; ++kk) {
+                edge(trsm[(size_t)i * nt + kk], u);
+                if (j != i) edge(trsm[(size_t)j * nt + kk], u);
+            }
+            last_writer[(size_t)i * nt + j] = u;
+        };
+        for (int j = k + 1; j < nt; ++j) {
+            const int kf = batched_until(j, W);
+            if (k >= kf) {
+                for (int i = j; i < nt; ++i) upd(i, j, k, k + 1);            // single step
+            } else if ((k + 1) % 4 == 0) {
+                for (int i = j; i < nt; ++i) upd(i, j, k - 3, k + 1);        // batch of four
+            }
+        }
+    }
+    const int n = (int)nodes.size();
+    // bottom levels (longest path to the end) in reverse generation order (generation order is topological)
+    for (int v = n - 1; v >= 0; --v) {
+        float b = 0;
+        for (int s : nodes[v].succ) b = std::max(b, nodes[s].prio);
+        nodes[v].prio = b + nodes[v].dur;
+    }
+    // list scheduling on `workers` identical workers
+    typedef std::pair<float, int> PI;
+    std::priority_queue<PI> ready;                                           // max bottom level first
+    std::priority_queue<PI, std::vector<PI>, std::greater<PI>> running;      // earliest finish first
+    for (int v = 0; v < n; ++v)
+        if (nodes[v].npred == 0) ready.push(PI(nodes[v].prio, v));
+    out.tasks.clear();
+    out.tasks.reserve(n);
+    float now = 0;
+    int freew = workers;
+    while ((int)out.tasks.size() < n) {
+        while (freew > 0 && !ready.empty()) {
+            const int v = ready.top().second;
+            ready.pop();
+            out.tasks.push_back(nodes[v].t);
+            running.push(PI(now + nodes[v].dur, v));
+            --freew;
+        }
+        if (running.empty()) break;                                          // cannot happen for a DAG
+        now = running.top().first;
+        while (!running.empty() && running.top().first <= now) {
+            const int v = running.top().second;
+            running.pop();
+            ++freew;
+            for (int s : nodes[v].succ)
+                if (--nodes[s].npred == 0) ready.push(PI(nodes[s].prio, s));
+        }
+    }
+    out.nt = nt;
+    out.window = W;
+}
+
+template <typename T>
+int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
+    const int nt = (int)(npad / NB);
+    static const int W = getenv("ALGP_DAG_WINDOW") ? atoi(getenv("ALGP_DAG_WINDOW")) : 4;
+    DagCache* dc = nullptr;
+    for (auto& e : c->dag_cache)
+        if (e.nt == nt) dc = &e;
+    if (!dc) {
+        hipDeviceProp_t prop;
+        ALGP_HIP(hipGetDeviceProperties(&prop, c->device));
+        DagSchedule sched;
+        dag_build_schedule(nt, W, 2 * prop.multiProcessorCount, sched);
+        if (c->dag_cache.size() >= 4) {                        // keep the four most recent sizes
+            ALGP_HIP(hipStreamSynchronize(c->cur));
+            hipFree(c->dag_cache.front().tasks.p);
+            c->dev_bytes -= (int64_t)c->dag_cache.front().tasks.cap;
+            c->dag_cache.erase(c->dag_cache.begin());
+        }
+        DagCache e;
+        e.nt = nt;
+        e.ntasks = (int)sched.tasks.size();
+        ALGP_TRY(ensure(c, e.tasks, sizeof(DagTask) * sched.tasks.size()));
+        ALGP_HIP(hipMemcpy(e.tasks.p, sched.tasks.data(), sizeof(DagTask) * sched.tasks.size(), hipMemcpyHostToDevice));
+        c->dag_cache.push_back(e);
+        dc = &c->dag_cache.back();
+    }
+    // per-launch state: tile versions, control words, per-block log-determinants (one zeroed block)
+    const size_t nver = (size_t)nt * nt;
+    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + 4) + sizeof(double) * nt + 16), 16);
+    ALGP_TRY(ensure(c, c->dag_state, state_bytes));
+    ALGP_HIP(hipMemsetAsync(c->dag_state.p, 0, state_bytes, c->cur));
+    DagArgs<T> g;
+    g.L = A;
+    g.ld = ld;
+    g.invD = invD;
+    g.tasks = (const DagTask*)dc->tasks.p;
+    g.ntasks = dc->ntasks;
+    g.nt = nt;
+    g.ld_blocks = (double*)c->dag_state.p;                     // doubles first (8-byte aligned)
+    g.ctrl = (int*)((char*)c->dag_state.p + sizeof(double) * nt);
+    g.ver = g.ctrl + 4;
+    g.info = info;
+    const double flops = (double)npad * npad * npad / 3.0;
+    {
+        ProfScope ps(c, ALGP_PROF_GEMM_CHOL_UPDATE, flops, sizeof(T) * (double)npad * npad);
+        int grid = 2 * 256;
+        if (grid > dc->ntasks) grid = dc->ntasks;
+        hipLaunchKernelGGL(chol_dag_kernel<T>, dim3(grid), dim3(256), 0, c->cur, g);
+        ALGP_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(dag_finish_kernel, dim3(1), dim3(64), 0, c->cur, g.ld_blocks, nt, g.ctrl, logdet_acc, info);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int cholesky_dag<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*);
+template int cholesky_dag<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*);
+
+void dag_release(algp_ctx* c) {
+    for (auto& e : c->dag_cache)
+        if (e.tasks.p) hipFree(e.tasks.p);
+    c->dag_cache.clear();
+}
+
+}  // namespace algp

@@ -44,6 +44,12 @@ struct PickRec {           // one committed greedy pick (needed to extend a remo
     double scale;          // 1/lambda (append) or sqrt(-gamma) (noise change)
 };
 
+struct DagCache {          // device copy of one task list of the dependency-driven Cholesky (chol_dag.hip)
+    int64_t nt;
+    DevBuf tasks;
+    int ntasks;
+};
+
 struct LazyPick {          // device copy of a committed pick for the lazy greedy refresh (vecops.hip)
     int64_t pool_idx;
     int64_t ncols;         // columns of V^T the pick's dot product covers = the column its entry goes to
@@ -61,10 +67,6 @@ struct algp_ctx {
     hipStream_t stream2 = nullptr;   // helper streams: independent row chunks of the candidate solve overlap on them
     hipStream_t stream3 = nullptr, stream4 = nullptr;
     int trsm_chunks = 3;
-    hipStream_t streamC = nullptr;   // high-priority stream: the factorisation inside algp_fit_and_solve
-    bool record_blk_events = false;  // cholesky_blocked records one event per factored 512-column block ...
-    bool gate_blk_events = false;    // ... and the candidate solve waits for block J's event before touching it
-    size_t blk_event_base = 16;
     hipStream_t cur = nullptr;       // stream the launch helpers currently target
     std::vector<hipEvent_t> sync_events;
     std::string err;
@@ -105,6 +107,8 @@ struct algp_ctx {
     // per candidate: sums over the kept columns [0, acc_cols) of V^T of v^2, v u, v w (incremental solve)
     algp::DevBuf acc3;
     algp::DevBuf splitk;                 // partial products of split-K launches (skinny solves)
+    std::vector<algp::DagCache> dag_cache;   // task lists of the dependency-driven Cholesky, per matrix size
+    algp::DevBuf dag_state;              // its per-launch tile versions / control words / per-block log-determinants
     int64_t acc_cols = 0, acc_M = -1;
     int64_t factor_rows_from_vt = 0;     // last factor update: rows of L taken from V^T instead of a triangular solve
     bool alpha_valid = false;            // alpha = L^-T z is computed on first use (scoring does not need it)
@@ -228,7 +232,9 @@ template <typename T>
 int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet_acc, int* info,
                       int64_t block_row0);
 
-// blocked right-looking Cholesky of the npad x npad matrix A (ld), inverse diagonal blocks to invD
+void dag_release(algp_ctx* c);   // frees the cached task lists of the dependency-driven Cholesky
+// Cholesky of the npad x npad matrix A (ld), inverse diagonal blocks to invD (one dependency-driven launch, or the
+// blocked right-looking launch sequence for very small / very large matrices)
 template <typename T>
 int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc,
                      int* info);

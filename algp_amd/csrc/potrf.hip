@@ -88,22 +88,14 @@ static int chol_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doub
     return ALGP_OK;
 }
 
-// Right-looking blocked Cholesky, two-level (512 / 128).
-//
-// Look-ahead (factor block column J+1 on a second stream while the main stream applies block J to
-// the rest) was built and measured in round 1 and is NOT used: the fp64 diagonal kernel needs 134 KB
-// of LDS, i.e. an empty CU, and the trailing-update GEMM keeps two 64 KB workgroups on every CU, so
-// the panel never starts before the GEMM drains (19.8 ms vs 17.6 ms serial at N = 10 000; reserving
-// CUs with a CU-masked stream: 22.1 ms).  It becomes useful once the diagonal kernel fits beside a
-// GEMM workgroup (<= 96 KB: lower-triangular 16 x 16 block storage).
+// Right-looking blocked Cholesky, two-level (512 / 128), as a sequence of launches: used for small matrices and
+// for matrices too large for the dependency-driven launch's task list (chol_dag.hip), which is the default in
+// between.  (Round 1 also measured a two-stream look-ahead of this sequence: no gain, 19.2 vs 18.9 ms at N = 10 000.)
 template <typename T>
 static int cholesky_serial(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
     for (int64_t j0 = 0; j0 < npad; j0 += WB) {
         const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
         ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, j0, w));
-        // rows [j0, j0+w) of L and their inverse diagonal blocks are final: a pipelined candidate solve
-        // (algp_fit_and_solve) may start on column block j0/WB
-        if (c->record_blk_events) ALGP_HIP(hipEventRecord(sync_event(c, c->blk_event_base + (size_t)(j0 / WB)), c->cur));
         const int64_t mrem = npad - (j0 + w);
         if (mrem > 0) {
             // trailing update with the whole block: A22 -= P_blk P_blk^T, K = w, lower tiles
@@ -116,60 +108,15 @@ static int cholesky_serial(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD,
     return ALGP_OK;
 }
 
-// One block of look-ahead: while the caller's stream applies block J to the columns right of block
-// J+1 (the bulk of the flops), a helper stream already factors block column J+1.
 template <typename T>
-static int cholesky_lookahead(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
-    const int64_t nblk = (npad + WB - 1) / WB;
-    hipStream_t s1 = c->cur, s2 = (c->cur == c->stream2) ? c->stream3 : c->stream2;
-    struct Restore {
-        algp_ctx* c;
-        hipStream_t s;
-        ~Restore() { c->cur = s; }
-    } restore{c, s1};
-    const size_t E = 40;                                          // sync_event slots of this routine
-    ALGP_HIP(hipEventRecord(sync_event(c, E), s1));
-    ALGP_HIP(hipStreamWaitEvent(s2, sync_event(c, E), 0));
-    c->cur = s2;
-    ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, 0, npad < WB ? npad : WB));
-    ALGP_HIP(hipEventRecord(sync_event(c, E + 1), s2));
-    size_t last = E + 1;
-    for (int64_t J = 0; J < nblk; ++J) {
-        const int64_t j0 = J * WB;
-        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB;
-        const int64_t r0 = j0 + w;
-        ALGP_HIP(hipStreamWaitEvent(s1, sync_event(c, E + 1 + 2 * (size_t)J), 0));      // panel J factored
-        if (c->record_blk_events) ALGP_HIP(hipEventRecord(sync_event(c, c->blk_event_base + (size_t)J), s1));
-        if (r0 >= npad) break;
-        const int64_t w2 = (npad - r0 < WB) ? npad - r0 : WB;
-        const T* Pb = A + r0 * ld + j0;
-        c->cur = s1;                                              // next block column first
-        ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, npad - r0, w2, w, (T)-1, Pb, ld, Pb, ld, (T)1,
-                                   A + r0 * ld + r0, ld, A + r0 * ld + r0, ld, 0));
-        ALGP_HIP(hipEventRecord(sync_event(c, E + 2 + 2 * (size_t)J), s1));
-        ALGP_HIP(hipStreamWaitEvent(s2, sync_event(c, E + 2 + 2 * (size_t)J), 0));
-        c->cur = s2;
-        ALGP_TRY(chol_panel<T>(c, A, npad, ld, invD, logdet_acc, info, r0, w2));
-        ALGP_HIP(hipEventRecord(sync_event(c, E + 3 + 2 * (size_t)J), s2));
-        last = E + 3 + 2 * (size_t)J;
-        const int64_t r1 = r0 + w2;
-        if (r1 < npad) {                                          // the rest, concurrently with that panel
-            c->cur = s1;
-            const T* Pc = A + r1 * ld + j0;
-            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_CHOL, npad - r1, npad - r1, w, (T)-1, Pc, ld, Pc, ld, (T)1,
-                                       A + r1 * ld + r1, ld, A + r1 * ld + r1, ld, 1));
-        }
-    }
-    ALGP_HIP(hipStreamWaitEvent(s1, sync_event(c, last), 0));
-    c->cur = s1;
-    return ALGP_OK;
-}
+int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info);
 
 template <typename T>
 int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
-    static const int la = getenv("ALGP_CHOL_LOOKAHEAD") ? atoi(getenv("ALGP_CHOL_LOOKAHEAD")) : 0;
-    if (la && npad >= 4 * WB && c->stream2 && c->stream3)
-        return cholesky_lookahead<T>(c, A, npad, ld, invD, logdet_acc, info);
+    // ALGP_CHOL_DAG=0 selects the launch sequence for every size (A/B runs, tests of the fallback)
+    static const int dag = getenv("ALGP_CHOL_DAG") ? atoi(getenv("ALGP_CHOL_DAG")) : 1;
+    const int64_t nt = npad / NB;
+    if (dag && nt >= 8 && nt <= 192) return cholesky_dag<T>(c, A, npad, ld, invD, logdet_acc, info);
     return cholesky_serial<T>(c, A, npad, ld, invD, logdet_acc, info);
 }
 template int cholesky_blocked<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*);
@@ -182,7 +129,7 @@ template <typename T>
 static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                      int64_t ldl, const T* invD, int64_t col_start) {
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
-    if (mpad <= 32 * NB && !c->gate_blk_events) {
+    if (mpad <= 32 * NB) {
         // A short X (a few test points): the left-looking order below would walk K up to npad inside
         // one or two workgroups (launch-latency bound).  Right-looking instead: solve one 128-column
         // block, then update ALL remaining columns with K = 128 -- (npad-k)/128 column tiles in parallel.
@@ -201,11 +148,10 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
         }
         return ALGP_OK;
     }
-    static const int64_t TWB = getenv("ALGP_TRSM_WB") ? atoll(getenv("ALGP_TRSM_WB")) : WB;   // outer block width
+    const int64_t TWB = WB;                                     // outer block width
     for (int64_t j0 = 0; j0 < npad; j0 += TWB) {
         const int64_t w = (npad - j0 < TWB) ? npad - j0 : TWB;
         if (j0 + w <= col_start) continue;
-        if (c->gate_blk_events) ALGP_HIP(hipStreamWaitEvent(c->cur, sync_event(c, c->blk_event_base + (size_t)(j0 / WB)), 0));
         const int64_t cs = j0 > col_start ? j0 : col_start;         // first column of this block to solve
         T* Xj = X + j0;
         if (j0 > 0)
@@ -268,40 +214,12 @@ template int syrk_upper<float>(algp_ctx*, int, const float*, int64_t, int64_t, f
 template int trinv_upper<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, const double*);
 template int trinv_upper<float>(algp_ctx*, int, float*, int64_t, int64_t, const float*, int64_t, const float*);
 
-// Divide and conquer over the columns [c0, c1) of X (contributions of the columns < c0 are already
-// applied):  solve the left half, subtract its product with the off-diagonal block of L from the right
-// half (ONE GEMM with n = K = half the range), solve the right half.  Same flops as the blocked sweep
-// with squarer GEMMs.  Measured in round 1 (N = 10 000, M = 100 000, fp64): same time (160.9 vs 161.3 ms)
-// but MORE HBM traffic (FETCH x2 + WRITE: 339 GB vs 200 GB per solve) -- the big off-diagonal blocks of L
-// (up to 5120 x 5120) fall out of the 4 MB L2s -- so the blocked sweep stays the default (ALGP_TRSM_MODE=1
-// selects this one).
-template <typename T>
-static int trsm_rec(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t ldl, const T* invD,
-                    int64_t c0, int64_t c1) {
-    if (c1 - c0 == NB) {
-        T* Xk = X + c0;
-        return gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (c0 / NB) * NB * NB, NB, (T)0, nullptr, 0,
-                                 Xk, ldx, 0);
-    }
-    const int64_t half = ((c1 - c0) / NB + 1) / 2 * NB;            // left part: ceil(blocks / 2)
-    const int64_t mid = c0 + half;
-    ALGP_TRY(trsm_rec<T>(c, klass, X, mpad, ldx, L, ldl, invD, c0, mid));
-    ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, c1 - mid, mid - c0, (T)-1, X + c0, ldx, L + mid * ldl + c0, ldl, (T)1,
-                               X + mid, ldx, X + mid, ldx, 0));
-    return trsm_rec<T>(c, klass, X, mpad, ldx, L, ldl, invD, mid, c1);
-}
-
+// (A divide-and-conquer order of this sweep was measured in round 1: same time, 339 GB instead of 200 GB of HBM
+// traffic per solve at N = 10 000, M = 100 000 -- the big off-diagonal blocks of L fall out of the 4 MB L2s -- and removed.)
 template <typename T>
 static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                      int64_t ldl, const T* invD, int64_t col_start) {
-    static const int mode = getenv("ALGP_TRSM_MODE") ? atoi(getenv("ALGP_TRSM_MODE")) : 0;   // 0 blocked, 1 recursive
-    if (mode == 0 || c->gate_blk_events || mpad <= 32 * NB)
-        return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start);
-    if (col_start >= npad) return ALGP_OK;
-    if (col_start > 0)          // the unsolved columns first receive the contributions of the kept ones
-        ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, npad - col_start, col_start, (T)-1, X, ldx, L + col_start * ldl, ldl,
-                                   (T)1, X + col_start, ldx, X + col_start, ldx, 0));
-    return trsm_rec<T>(c, klass, X, mpad, ldx, L, ldl, invD, col_start, npad);
+    return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start);
 }
 
 static hipEvent_t sync_event(algp_ctx* c, size_t i) {
