@@ -4,7 +4,9 @@
 // right-looking factorisation of potrf.hip is a chain of short launches (diagonal block on one workgroup,
 // K = 128 panel launches, one K = 512 update per 512 columns): at N = 10 000 the chip is mostly idle
 // (19.7 TFLOP/s, round 1).  Here the same arithmetic is a list of tile tasks over 128 x 128 tiles
-//     DIAG(k)           L_kk = chol(S_kk), X_kk = inv(L_kk)                  (diag.h, one workgroup)
+//     CHAIN(k)          L_kk = chol(S_kk), X_kk = inv(L_kk) (diag.h), then the two tile products the next
+//                       diagonal block waits for: TRSM(k+1,k) and UPD(k+1,k+1,k,k+1) -- all steps k by ONE workgroup
+//                       (the first to arrive), with no hand-off in between and its CU to itself
 //     TRSM(i,k)         L_ik = S_ik X_kk^T                                   (MFMA tile product, K = 128)
 //     UPD(i,j,k0,k1)    S_ij -= L_i,[k0,k1) L_j,[k0,k1)^T                    (MFMA tile product, K = 128 (k1-k0))
 // executed by persistent workgroups that draw tasks from ONE ordered list with an atomic ticket.  A task waits
@@ -30,7 +32,7 @@
 
 namespace algp {
 
-enum { DAG_DIAG = 0, DAG_TRSM = 1, DAG_UPD = 2 };
+enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2 };
 struct DagTask {
     int type, i, j, kk;                                        // kk = (k0 << 16) | k1
 };
@@ -43,7 +45,7 @@ struct DagArgs {
     const DagTask* tasks;
     int ntasks, nt;
     int* ver;                                                  // nt x nt tile versions (number of column steps applied)
-    int* ctrl;                                                 // [0] ticket, [1] abort code, [2] spins (diagnostic)
+    int* ctrl;                                                 // [0] ticket, [1] abort code, [2] the chain's CU, [3] arrival order
     double* ld_blocks;                                         // per diagonal block: sum(log pivots)
     int* info;
 };
@@ -52,8 +54,18 @@ struct DagArgs {
 #ifdef ALGP_DAG_DEBUG
 __device__ int g_dag_dbg[4 * 1024];
 #define DAG_DBG(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 1024) __hip_atomic_store(&g_dag_dbg[4 * blockIdx.x + (slot)], (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+// per task: 100 MHz stamps at ticket / inputs ready / computed / published, and the workgroup + XCD that ran it
+__device__ unsigned long long g_dag_trace[4 * 262144];
+__device__ unsigned long long g_dag_chain[16 * 1024];         // per chain step: stamps inside the fused task
+#define DAG_CHAINT(k, slot) do { if (threadIdx.x == 0 && (k) < 1024) g_dag_chain[16 * (k) + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ int g_dag_who[262144];
+#define DAG_TRACE(t, slot) do { if (threadIdx.x == 0 && (t) < 262144) g_dag_trace[4 * (t) + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DAG_WHO(t) do { if (threadIdx.x == 0 && (t) < 262144) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_dag_who[t] = (int)((blockIdx.x << 4) | (xcc & 15)); } } while (0)
 #else
 #define DAG_DBG(slot, val) do { } while (0)
+#define DAG_TRACE(t, slot) do { } while (0)
+#define DAG_WHO(t) do { } while (0)
+#define DAG_CHAINT(k, slot) do { } while (0)
 #endif
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -129,22 +141,165 @@ __device__ __forceinline__ void tile_mainloop(char* smem, const T* A0, int64_t l
 }
 
 
+// ---- the three building blocks of a task, called by all 256 threads ----
+// Wait until every listed tile version has reached its target: lane l of wave 0 polls dependency l (di, dj, want are
+// per-lane values, meaningful for lanes < ndeps).  Returns false when the launch is being aborted (a spin ran into
+// its time limit here or elsewhere); the caller then leaves the task loop.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
+__device__ __forceinline__ bool dag_wait(const DagArgs<T>& g, int ticket, int ndeps, int di, int dj, int want, int* s_ok) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) {
+        const bool mine = lane < ndeps;
+        int* addr = g.ver + (mine ? (int64_t)di * g.nt + dj : 0);
+        bool ok = false;
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0;; ++spins) {
+            const int v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = __all(!mine || v >= want);
+            if (ok) break;
+            if (__hip_atomic_load(&g.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t_start > 200000000ull) {   // 2 s at 100 MHz
+                if (lane == 0) atomicCAS(&g.ctrl[1], 0, ticket + 1);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (ok) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (lane == 0) *s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = __builtin_amdgcn_readfirstlane(*s_ok) != 0;
+    __syncthreads();                                           // s_ok may be rewritten by the next wait
+    return ok;
+}
+// Publish tile (i, j) at version `ver`: all stores drained, barrier, one release, drain, version store.
+template <typename T>
+__device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, int ver) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {                                           // a wave-uniform branch (see the note at the ticket)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(g.ver + (int64_t)i * g.nt + j, ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// UPD: tile (i, j) -= L_i,[k0,k1) L_j,[k0,k1)^T.  TRSM (upd == false): tile (i, j) <- tile (i, j) X_jj^T, in place.
+template <typename T>
+__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
+    const int lane = threadIdx.x & 63, fr = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    T* Cij = g.L + (int64_t)ti * 128 * g.ld + (int64_t)tj * 128;
+    acc_t acc[4][4];
+    const T* A0;
+    const T* B0;
+    int64_t ldb;
+    int nkt;
+    if (upd) {
+        // acc = -C, then acc += A B^T, then C = -acc
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = -Cij[gi * g.ld + wc * 64 + j * 16 + fr];
+            }
+        A0 = g.L + (int64_t)ti * 128 * g.ld + (int64_t)k0 * 128;
+        B0 = g.L + (int64_t)tj * 128 * g.ld + (int64_t)k0 * 128;
+        ldb = g.ld;
+        nkt = (k1 - k0) * (128 / (4 * F::EPC));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+        A0 = Cij;                                              // in place: every read of the tile precedes the stores
+        B0 = g.invD + (int64_t)tj * 128 * 128;
+        ldb = 128;
+        nkt = 128 / (4 * F::EPC);
+    }
+    tile_mainloop<T>(smem, A0, g.ld, B0, ldb, nkt, acc);
+    const T sgn = upd ? (T)-1 : (T)1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cij[gi * g.ld + wc * 64 + j * 16 + fr] = sgn * acc[i][j][r];
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     __shared__ __attribute__((aligned(1024))) union {
         DiagShared<T> diag;
         char gemm[4 * 16384];
     } sm;
     __shared__ int s_ticket, s_ok;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15;
     const int nt = g.nt;
 
+    // ---- roles: the first workgroup to arrive runs the whole diagonal chain (its steps depend on each other anyway);
+    // it publishes which CU it sits on, and the workgroup that shares that CU retires after its current task: the
+    // chain's leaf arithmetic and its two K = 128 products run twice as fast with the CU to themselves (measured:
+    // diagonal block 87 -> us, products 24-27 -> us), and one idle slot of 512 costs the bulk nothing.
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int cu_key = (int)((((hwid >> 8) & 0xff) | ((xcc & 0xf) << 8)) + 1);       // (se, sh, cu, xcc), never 0
+    if (tid == 0) s_ticket = atomicAdd(&g.ctrl[3], 1);
+    __syncthreads();
+    const int role = __builtin_amdgcn_readfirstlane(s_ticket);
+    __syncthreads();
+    if (role == 0) {
+        if (tid == 0) __hip_atomic_store(&g.ctrl[2], cu_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_setprio(3);
+        for (int k = 0; k < nt; ++k) {
+            // L_kk, X_kk  ->  L_(k+1)k = S_(k+1)k X_kk^T  ->  S_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, no hand-off in between
+            if (!dag_wait<T>(g, -1 - k, 1, k, k, k, &s_ok)) break;
+            DAG_CHAINT(k, 0);
+            T* Akk = g.L + (int64_t)k * 128 * g.ld + (int64_t)k * 128;
+            diag128_factor<T>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, g.ld_blocks + k, false, g.info,
+                              (int64_t)k * 128);
+            DAG_CHAINT(k, 1);
+            dag_publish<T>(g, k, k, k + 1);
+            DAG_CHAINT(k, 2);
+            if (k + 1 < nt) {
+                if (!dag_wait<T>(g, -1 - k, 1, k + 1, k, k, &s_ok)) break;
+                DAG_CHAINT(k, 3);
+                dag_tile_op<T>(g, sm.gemm, false, k + 1, k, k, k + 1);
+                DAG_CHAINT(k, 4);
+                dag_publish<T>(g, k + 1, k, k + 1);
+                DAG_CHAINT(k, 5);
+                if (!dag_wait<T>(g, -1 - k, 1, k + 1, k + 1, k, &s_ok)) break;
+                DAG_CHAINT(k, 6);
+                dag_tile_op<T>(g, sm.gemm, true, k + 1, k + 1, k, k + 1);
+                DAG_CHAINT(k, 7);
+                dag_publish<T>(g, k + 1, k + 1, k + 1);
+                DAG_CHAINT(k, 8);
+            }
+        }
+        return;
+    }
+
     for (;;) {
-        if (tid == 0) s_ticket = atomicAdd(&g.ctrl[0], 1);
+        if (tid == 0) {
+            const bool beside_chain = __hip_atomic_load(&g.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
+            s_ticket = beside_chain ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
+        }
         __syncthreads();                                       // also: every wave is done with the previous task's LDS
         // wave-uniform in fact, and told so to the compiler: with a (formally) divergent loop exit hipcc lets the
         // lanes that stay in the loop run ahead into the next iteration's barrier before lane 0 has published
@@ -152,111 +307,33 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         DAG_DBG(0, t);
         DAG_DBG(1, 1);
         if (t >= g.ntasks) break;
+        DAG_TRACE(t, 0);
+        DAG_WHO(t);
         const DagTask task = g.tasks[t];
         const int type = task.type, ti = task.i, tj = task.j, k0 = task.kk >> 16, k1 = task.kk & 0xffff;
 
-        // ---- wait for the inputs: lane l of wave 0 polls dependency l ----
-        if (wave == 0) {
-            int ndeps, di = ti, dj = tj, want = 0;
-            if (type == DAG_DIAG) {
-                ndeps = 1; want = ti;                          // tile (k,k) has received its k updates
-            } else if (type == DAG_TRSM) {
-                ndeps = 2;
-                if (lane == 0) want = tj;                      // tile (i,k) updated k times
-                else { di = tj; dj = tj; want = tj + 1; }      // diagonal block k factored
-            } else {
-                const int n = k1 - k0;
-                ndeps = 1 + (ti == tj ? n : 2 * n);
-                if (lane == 0) want = k0;
-                else if (lane <= n) { dj = k0 + lane - 1; want = dj + 1; }
-                else { di = tj; dj = k0 + lane - n - 1; want = dj + 1; }
-            }
-            const bool mine = lane < ndeps;
-            int* addr = g.ver + (mine ? (int64_t)di * nt + dj : 0);
-            bool ok = false;
-            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-            for (unsigned spins = 0;; ++spins) {
-                const int v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = __all(!mine || v >= want);
-                if (ok) break;
-                if (__hip_atomic_load(&g.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t_start > 200000000ull) {   // 2 s at 100 MHz
-                    if (lane == 0) atomicCAS(&g.ctrl[1], 0, t + 1);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (ok) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            if (lane == 0) s_ok = ok ? 1 : 0;
-        }
-        __syncthreads();
-        if (!__builtin_amdgcn_readfirstlane(s_ok)) break;
-        DAG_DBG(1, 2);
-
-        if (type == DAG_DIAG) {
-            const int k = ti;
-            T* Akk = g.L + (int64_t)k * 128 * g.ld + (int64_t)k * 128;
-            diag128_factor<T>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, g.ld_blocks + k, false, g.info,
-                              (int64_t)k * 128);
+        // ---- wait for the inputs ----
+        int ndeps, di = ti, dj = tj, want = 0;
+        if (type == DAG_TRSM) {
+            ndeps = 2;
+            if (lane == 0) want = tj;                          // tile (i,k) updated k times
+            else { di = tj; dj = tj; want = tj + 1; }          // diagonal block k factored
         } else {
-            T* Cij = g.L + (int64_t)ti * 128 * g.ld + (int64_t)tj * 128;
-            acc_t acc[4][4];
-            const T* A0;
-            const T* B0;
-            int64_t ldb;
-            int nkt;
-            if (type == DAG_UPD) {
-                // acc = -C, then acc += A B^T, then C = -acc
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j][r] = -Cij[gi * g.ld + wc * 64 + j * 16 + fr];
-                    }
-                A0 = g.L + (int64_t)ti * 128 * g.ld + (int64_t)k0 * 128;
-                B0 = g.L + (int64_t)tj * 128 * g.ld + (int64_t)k0 * 128;
-                ldb = g.ld;
-                nkt = (k1 - k0) * (128 / (4 * F::EPC));
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
-                A0 = Cij;                                      // in place: every read of the tile precedes the stores
-                B0 = g.invD + (int64_t)tj * 128 * 128;
-                ldb = 128;
-                nkt = 128 / (4 * F::EPC);
-            }
-            tile_mainloop<T>(sm.gemm, A0, g.ld, B0, ldb, nkt, acc);
-            const T sgn = (type == DAG_UPD) ? (T)-1 : (T)1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Cij[gi * g.ld + wc * 64 + j * 16 + fr] = sgn * acc[i][j][r];
-                }
+            const int n = k1 - k0;
+            ndeps = 1 + (ti == tj ? n : 2 * n);
+            if (lane == 0) want = k0;
+            else if (lane <= n) { dj = k0 + lane - 1; want = dj + 1; }
+            else { di = tj; dj = k0 + lane - n - 1; want = dj + 1; }
         }
-        // ---- publish: all stores drained, barrier, one release, drain, version store ----
+        if (!dag_wait<T>(g, t, ndeps, di, dj, want, &s_ok)) break;
+        DAG_DBG(1, 2);
+        DAG_TRACE(t, 1);
+        dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1);
         DAG_DBG(1, 3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (wave == 0) {                                       // a wave-uniform branch (see the note at the ticket)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int newver = (type == DAG_UPD) ? k1 : tj + 1;
-            if (lane == 0)
-                __hip_atomic_store(g.ver + (int64_t)ti * nt + tj, newver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        DAG_TRACE(t, 2);
+        dag_publish<T>(g, ti, tj, (type == DAG_UPD) ? k1 : tj + 1);
         DAG_DBG(1, 4);
+        DAG_TRACE(t, 3);
     }
     DAG_DBG(1, 5);
 }
@@ -290,6 +367,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         DagTask t;
         float dur, prio;
         int npred;
+        bool on_chain = false;
         std::vector<int> succ;
     };
     std::vector<Node> nodes;
@@ -308,13 +386,28 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         nodes[from].succ.push_back(to);
         nodes[to].npred++;
     };
-    // durations in microseconds (two workgroups share a CU's matrix cores): only their proportions matter
-    const float D_DIAG = 55.f, D_OP = 28.f, D_OVH = 9.f;
+    // durations in microseconds as measured at N = 10 000 (bulk workgroups share a CU's matrix cores in pairs, the
+    // chain has its CU to itself); only their proportions matter
+    const float D_DIAG = 50.f, D_CHAIN_OP = 24.f, D_OP = 33.f, D_OVH = 5.f;
     for (int k = 0; k < nt; ++k) {
-        const int d = add(DAG_DIAG, k, k, k, k + 1, D_DIAG);
+        // the chain's three links of column step k: never ticketed (one dedicated workgroup runs them all), but part
+        // of the simulation, where they start the moment their inputs are there (ON_CHAIN)
+        const int d = add(DAG_CHAIN, k, k, k, k + 1, D_DIAG);
+        nodes[d].on_chain = true;
         edge(last_writer[(size_t)k * nt + k], d);
-        diag[k] = d;
-        for (int i = k + 1; i < nt; ++i) {
+        if (k + 1 < nt) {
+            const int b = add(DAG_CHAIN, k + 1, k, k, k + 1, D_CHAIN_OP);          // TRSM(k+1,k)
+            nodes[b].on_chain = true;
+            edge(d, b);
+            edge(last_writer[(size_t)(k + 1) * nt + k], b);
+            trsm[(size_t)(k + 1) * nt + k] = b;
+            const int c2 = add(DAG_CHAIN, k + 1, k + 1, k, k + 1, D_CHAIN_OP);     // UPD(k+1,k+1,k,k+1)
+            nodes[c2].on_chain = true;
+            edge(b, c2);
+            edge(last_writer[(size_t)(k + 1) * nt + (k + 1)], c2);
+            last_writer[(size_t)(k + 1) * nt + (k + 1)] = c2;
+        }
+        for (int i = k + 2; i < nt; ++i) {
             const int tr = add(DAG_TRSM, i, k, k, k + 1, D_OP + D_OVH);
             edge(d, tr);
             edge(last_writer[(size_t)i * nt + k], tr);
@@ -332,7 +425,8 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         for (int j = k + 1; j < nt; ++j) {
             const int kf = batched_until(j, W);
             if (k >= kf) {
-                for (int i = j; i < nt; ++i) upd(i, j, k, k + 1);            // single step
+                for (int i = j; i < nt; ++i)
+                    if (!(i == k + 1 && j == k + 1)) upd(i, j, k, k + 1);    // single step ((k+1,k+1) is CHAIN(k)'s)
             } else if ((k + 1) % 4 == 0) {
                 for (int i = j; i < nt; ++i) upd(i, j, k - 3, k + 1);        // batch of four
             }
@@ -349,17 +443,26 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     typedef std::pair<float, int> PI;
     std::priority_queue<PI> ready;                                           // max bottom level first
     std::priority_queue<PI, std::vector<PI>, std::greater<PI>> running;      // earliest finish first
-    for (int v = 0; v < n; ++v)
-        if (nodes[v].npred == 0) ready.push(PI(nodes[v].prio, v));
     out.tasks.clear();
     out.tasks.reserve(n);
     float now = 0;
-    int freew = workers;
-    while ((int)out.tasks.size() < n) {
+    int freew = workers - 2, started = 0;                                    // the chain workgroup and its retired CU neighbour
+    auto release = [&](int v) {                                              // all inputs of v are there
+        if (nodes[v].on_chain) {
+            running.push(PI(now + nodes[v].dur, v));
+            ++started;
+        } else {
+            ready.push(PI(nodes[v].prio, v));
+        }
+    };
+    for (int v = 0; v < n; ++v)
+        if (nodes[v].npred == 0) release(v);
+    while (started < n) {
         while (freew > 0 && !ready.empty()) {
             const int v = ready.top().second;
             ready.pop();
             out.tasks.push_back(nodes[v].t);
+            ++started;
             running.push(PI(now + nodes[v].dur, v));
             --freew;
         }
@@ -368,9 +471,9 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         while (!running.empty() && running.top().first <= now) {
             const int v = running.top().second;
             running.pop();
-            ++freew;
-            for (int s : nodes[v].succ)
-                if (--nodes[s].npred == 0) ready.push(PI(nodes[s].prio, s));
+            if (!nodes[v].on_chain) ++freew;
+            for (int s2 : nodes[v].succ)
+                if (--nodes[s2].npred == 0) release(s2);
         }
     }
     out.nt = nt;
