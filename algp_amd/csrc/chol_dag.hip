@@ -33,6 +33,9 @@
 namespace algp {
 
 enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2 };
+constexpr int DAG_STRIPS = 4;                                 // row strips of a 128-row tile product on the chain
+constexpr int DAG_TEAM = 1 + DAG_STRIPS;                      // workgroups on the diagonal chain: leader + one helper per strip
+constexpr int DAG_CTRL = 16;                                  // control words
 struct DagTask {
     int type, i, j, kk;                                        // kk = (k0 << 16) | k1
 };
@@ -45,7 +48,8 @@ struct DagArgs {
     const DagTask* tasks;
     int ntasks, nt;
     int* ver;                                                  // nt x nt tile versions (number of column steps applied)
-    int* ctrl;                                                 // [0] ticket, [1] abort code, [2] the chain's CU, [3] arrival order
+    int* ctrl;                                                 // [0] ticket, [1] abort code, [3] arrival order, [8..8+DAG_TEAM) the team's CUs
+    int* cnt;                                                  // per column step: strips published of the five team products
     double* ld_blocks;                                         // per diagonal block: sum(log pivots)
     int* info;
 };
@@ -142,20 +146,20 @@ __device__ __forceinline__ void tile_mainloop(char* smem, const T* A0, int64_t l
 
 
 // ---- the three building blocks of a task, called by all 256 threads ----
-// Wait until every listed tile version has reached its target: lane l of wave 0 polls dependency l (di, dj, want are
-// per-lane values, meaningful for lanes < ndeps).  Returns false when the launch is being aborted (a spin ran into
-// its time limit here or elsewhere); the caller then leaves the task loop.
+// Wait until every listed word has reached its target: lane l of wave 0 polls dependency l (addr / want are per-lane
+// values; addr == nullptr: nothing to wait for in this lane).  Returns false when the launch is being aborted (a spin
+// ran into its time limit here or elsewhere); the caller then leaves its task loop.
 template <typename T>
-__device__ __forceinline__ bool dag_wait(const DagArgs<T>& g, int ticket, int ndeps, int di, int dj, int want, int* s_ok) {
+__device__ __forceinline__ bool dag_wait(const DagArgs<T>& g, int ticket, const int* addr, int want, int* s_ok) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave == 0) {
-        const bool mine = lane < ndeps;
-        int* addr = g.ver + (mine ? (int64_t)di * g.nt + dj : 0);
+        const bool mine = addr != nullptr;
+        const int* a = mine ? addr : g.ctrl;
         bool ok = false;
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         for (unsigned spins = 0;; ++spins) {
-            const int v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int v = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = __all(!mine || v >= want);
             if (ok) break;
             if (__hip_atomic_load(&g.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -176,6 +180,8 @@ __device__ __forceinline__ bool dag_wait(const DagArgs<T>& g, int ticket, int nd
     __syncthreads();                                           // s_ok may be rewritten by the next wait
     return ok;
 }
+template <typename T>
+__device__ __forceinline__ const int* dag_ver(const DagArgs<T>& g, int i, int j) { return g.ver + (int64_t)i * g.nt + j; }
 // Publish tile (i, j) at version `ver`: all stores drained, barrier, one release, drain, version store.
 template <typename T>
 __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, int ver) {
@@ -242,6 +248,118 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
         }
 }
 
+// One of `parts` workgroups that share a tile publishes its part: release as in dag_publish, then an agent-scope add
+// to the tile's arrival counter; the workgroup whose add comes last publishes the tile's version for everybody else.
+template <typename T>
+__device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* counter, int parts, int i, int j, int ver) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == parts - 1)
+                __hip_atomic_store(g.ver + (int64_t)i * g.nt + j, ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- 32 x 128 strip product acc += A_strip B^T (A_strip: 32 rows, B: 128 rows, both k-contiguous): the chain's two
+// K = 128 products cut into four row strips, one per chain workgroup.  Same LDS-DMA pipeline as tile_mainloop; a stage
+// is 4 KB of A (wave w stages rows 8w..8w+7 with its lower 32 lanes; the upper lanes' copies land in the unused half
+// of the wave's 1 KB) + 8 KB of B; wave w owns output columns 32w..32w+31 (2 x 2 MFMA tiles).
+template <typename T>
+__device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t lda, const T* B0, int64_t ldb, int nkt,
+                                               typename MF<T>::acc_t (&acc)[2][2]) {
+    using F = MF<T>;
+    using chunk_t = typename F::chunk_t;
+    constexpr int EPC = F::EPC;
+    constexpr int BK = 4 * EPC;
+    constexpr int NST = 4, STB = 12288;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = lane >> 2;
+    const int bchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const int arow = 8 * wave + (srow & 7);
+    const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
+    const T* Ag = A0 + (int64_t)arow * lda + achunk * EPC;
+    const T* Bg = B0 + (int64_t)(32 * wave + srow) * ldb + bchunk * EPC;
+    auto stage = [&](int st, int kt) {
+        char* As = smem + st * STB + wave * 1024;
+        char* Bs = smem + st * STB + 4096 + wave * 2048;
+        __builtin_amdgcn_global_load_lds((glb_vp)(Ag + (int64_t)kt * BK), (lds_vp)As, 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(Bg + (int64_t)(16 * i) * ldb + (int64_t)kt * BK),
+                                             (lds_vp)(Bs + i * 1024), 16, 0, 0);
+    };
+    const int fr = lane & 15, fg = lane >> 4;
+    const int coff = ((fg ^ ((fr >> 2) & 3)) << 4);
+    // A row 16 i + fr sits in the 1 KB of wave (2 i + (fr >> 3)), local row fr & 7
+    const int aoff = (fr >> 3) * 1024 + (fr & 7) * 64 + coff;
+    const int boff = 4096 + (32 * wave + fr) * 64 + coff;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nkt) stage(t, t);
+    int st = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int younger = nkt - 1 - kt;
+        if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F76);       // vmcnt(6): three DMA per wave and stage
+        else if (younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        chunk_t a[2], b[2];
+        const char* base = smem + st * STB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const chunk_t*>(base + aoff + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const chunk_t*>(base + boff + j * 1024);
+        if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+        st = (st + 1 == NST) ? 0 : st + 1;
+    }
+}
+// strip `part` (rows 32 part .. 32 part + 31) of: UPD  tile (ti, tj) -= L_(ti,k) L_(tj,k)^T
+//                                                TRSM tile (ti, k) <- tile (ti, k) X_kk^T  (in place; tj unused)
+template <typename T>
+__device__ __forceinline__ void dag_strip_op(const DagArgs<T>& g, char* smem, bool upd, int part, int ti, int tj, int k) {
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    const int lane = threadIdx.x & 63, fr = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    T* Lik = g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)k * 128;      // the strip of tile (ti, k)
+    T* Out = upd ? g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)tj * 128 : Lik;
+    acc_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = i * 16 + F::row_of(lane, r);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j][r] = upd ? -Out[gi * g.ld + wave * 32 + j * 16 + fr] : (T)0;
+        }
+    const T* B0 = upd ? g.L + (int64_t)tj * 128 * g.ld + (int64_t)k * 128 : g.invD + (int64_t)k * 128 * 128;
+    strip_mainloop<T>(smem, Lik, g.ld, B0, upd ? g.ld : 128, 128 / (4 * F::EPC), acc);
+    const T sgn = upd ? (T)-1 : (T)1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = i * 16 + F::row_of(lane, r);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Out[gi * g.ld + wave * 32 + j * 16 + fr] = sgn * acc[i][j][r];
+        }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     __shared__ __attribute__((aligned(1024))) union {
@@ -252,10 +370,13 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int nt = g.nt;
 
-    // ---- roles: the first workgroup to arrive runs the whole diagonal chain (its steps depend on each other anyway);
-    // it publishes which CU it sits on, and the workgroup that shares that CU retires after its current task: the
-    // chain's leaf arithmetic and its two K = 128 products run twice as fast with the CU to themselves (measured:
-    // diagonal block 87 -> us, products 24-27 -> us), and one idle slot of 512 costs the bulk nothing.
+    // ---- roles: the first DAG_TEAM workgroups to arrive are the chain team.  The leader (first) factors every diagonal
+    // block.  The DAG_STRIPS helpers cut the K = 128 products around the diagonal into row strips, one per helper:
+    // the two the next diagonal block waits for, TRSM(k+1,k) and UPD(k+1,k+1,k), and -- while the leader factors
+    // that block -- the three that feed the chain's next step, TRSM(k+2,k), UPD(k+2,k+1,k), UPD(k+2,k+2,k) (left to
+    // bulk workgroups these arrived 10-30 us late at every step).  Each member publishes which CU it sits on and the
+    // workgroup that shares that CU retires after its current task: with the CU to themselves the leaf arithmetic
+    // and the products run twice as fast (diagonal block 87 -> 44 us), and a few idle slots of 512 cost the bulk nothing.
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -264,41 +385,69 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(s_ticket);
     __syncthreads();
-    if (role == 0) {
-        if (tid == 0) __hip_atomic_store(&g.ctrl[2], cu_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (role < DAG_TEAM) {
+        if (tid == 0) __hip_atomic_store(&g.ctrl[8 + role], cu_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(3);
-        for (int k = 0; k < nt; ++k) {
-            // L_kk, X_kk  ->  L_(k+1)k = S_(k+1)k X_kk^T  ->  S_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, no hand-off in between
-            if (!dag_wait<T>(g, -1 - k, 1, k, k, k, &s_ok)) break;
-            DAG_CHAINT(k, 0);
-            T* Akk = g.L + (int64_t)k * 128 * g.ld + (int64_t)k * 128;
-            diag128_factor<T>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, g.ld_blocks + k, false, g.info,
-                              (int64_t)k * 128);
-            DAG_CHAINT(k, 1);
-            dag_publish<T>(g, k, k, k + 1);
-            DAG_CHAINT(k, 2);
-            if (k + 1 < nt) {
-                if (!dag_wait<T>(g, -1 - k, 1, k + 1, k, k, &s_ok)) break;
-                DAG_CHAINT(k, 3);
-                dag_tile_op<T>(g, sm.gemm, false, k + 1, k, k, k + 1);
-                DAG_CHAINT(k, 4);
-                dag_publish<T>(g, k + 1, k, k + 1);
-                DAG_CHAINT(k, 5);
-                if (!dag_wait<T>(g, -1 - k, 1, k + 1, k + 1, k, &s_ok)) break;
-                DAG_CHAINT(k, 6);
-                dag_tile_op<T>(g, sm.gemm, true, k + 1, k + 1, k, k + 1);
-                DAG_CHAINT(k, 7);
-                dag_publish<T>(g, k + 1, k + 1, k + 1);
-                DAG_CHAINT(k, 8);
+        if (role == 0) {
+            for (int k = 0; k < nt; ++k) {
+                if (!dag_wait<T>(g, -1 - k, lane == 0 ? dag_ver(g, k, k) : nullptr, k, &s_ok)) break;
+                DAG_CHAINT(k, 0);
+                T* Akk = g.L + (int64_t)k * 128 * g.ld + (int64_t)k * 128;
+                diag128_factor<T>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, g.ld_blocks + k, false, g.info,
+                                  (int64_t)k * 128);
+                DAG_CHAINT(k, 1);
+                dag_publish<T>(g, k, k, k + 1);
+                DAG_CHAINT(k, 2);
             }
+            return;
+        }
+        const int part = role - 1;
+        const bool stamp = role == 1;
+        for (int k = 0; k + 1 < nt; ++k) {
+            int* cnt = g.cnt + 5 * k;
+            // L_(k+1)k = S_(k+1)k X_kk^T: needs X_kk and the tile updated k times
+            if (!dag_wait<T>(g, -1 - k, lane == 0 ? dag_ver(g, k, k) : (lane == 1 ? dag_ver(g, k + 1, k) : nullptr),
+                             lane == 0 ? k + 1 : k, &s_ok)) break;
+            if (stamp) DAG_CHAINT(k, 3);
+            dag_strip_op<T>(g, sm.gemm, false, part, k + 1, k, k);
+            if (stamp) DAG_CHAINT(k, 4);
+            dag_publish_part<T>(g, cnt + 0, DAG_STRIPS, k + 1, k, k + 1);
+            if (stamp) DAG_CHAINT(k, 5);
+            // S_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T: needs every strip of L_(k+1)k
+            if (!dag_wait<T>(g, -1 - k, lane == 0 ? cnt + 0 : (lane == 1 ? dag_ver(g, k + 1, k + 1) : nullptr),
+                             lane == 0 ? DAG_STRIPS : k, &s_ok)) break;
+            if (stamp) DAG_CHAINT(k, 6);
+            dag_strip_op<T>(g, sm.gemm, true, part, k + 1, k + 1, k);
+            if (stamp) DAG_CHAINT(k, 7);
+            dag_publish_part<T>(g, cnt + 1, DAG_STRIPS, k + 1, k + 1, k + 1);
+            if (stamp) DAG_CHAINT(k, 8);
+            if (k + 2 >= nt) continue;
+            // row k+2, in the shadow of the next diagonal block: L_(k+2)k, then its updates of (k+2,k+1) and (k+2,k+2)
+            if (!dag_wait<T>(g, -1 - k, lane == 0 ? dag_ver(g, k + 2, k) : nullptr, k, &s_ok)) break;
+            dag_strip_op<T>(g, sm.gemm, false, part, k + 2, k, k);
+            dag_publish_part<T>(g, cnt + 2, DAG_STRIPS, k + 2, k, k + 1);
+            if (stamp) DAG_CHAINT(k, 9);
+            if (!dag_wait<T>(g, -1 - k, lane == 0 ? cnt + 2 : (lane == 1 ? dag_ver(g, k + 2, k + 1) : nullptr),
+                             lane == 0 ? DAG_STRIPS : k, &s_ok)) break;
+            dag_strip_op<T>(g, sm.gemm, true, part, k + 2, k + 1, k);
+            dag_publish_part<T>(g, cnt + 3, DAG_STRIPS, k + 2, k + 1, k + 1);
+            if (stamp) DAG_CHAINT(k, 10);
+            if (!dag_wait<T>(g, -1 - k, lane == 0 ? dag_ver(g, k + 2, k + 2) : nullptr, k, &s_ok)) break;
+            dag_strip_op<T>(g, sm.gemm, true, part, k + 2, k + 2, k);
+            dag_publish_part<T>(g, cnt + 4, DAG_STRIPS, k + 2, k + 2, k + 1);
+            if (stamp) DAG_CHAINT(k, 11);
         }
         return;
     }
 
+    // ---- everybody else draws tickets from the list ----
     for (;;) {
-        if (tid == 0) {
-            const bool beside_chain = __hip_atomic_load(&g.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
-            s_ticket = beside_chain ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
+        if (tid < 64) {
+            // a bulk workgroup that shares its CU with a team or pool member retires
+            // a workgroup that shares its CU with a team member retires
+            bool beside = lane < DAG_TEAM && __hip_atomic_load(&g.ctrl[8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
+            beside = __any(beside);
+            if (tid == 0) s_ticket = beside ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
         }
         __syncthreads();                                       // also: every wave is done with the previous task's LDS
         // wave-uniform in fact, and told so to the compiler: with a (formally) divergent loop exit hipcc lets the
@@ -312,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         const DagTask task = g.tasks[t];
         const int type = task.type, ti = task.i, tj = task.j, k0 = task.kk >> 16, k1 = task.kk & 0xffff;
 
-        // ---- wait for the inputs ----
+        // ---- wait for the inputs: lane l polls dependency l ----
         int ndeps, di = ti, dj = tj, want = 0;
         if (type == DAG_TRSM) {
             ndeps = 2;
@@ -325,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
             else if (lane <= n) { dj = k0 + lane - 1; want = dj + 1; }
             else { di = tj; dj = k0 + lane - n - 1; want = dj + 1; }
         }
-        if (!dag_wait<T>(g, t, ndeps, di, dj, want, &s_ok)) break;
+        if (!dag_wait<T>(g, t, lane < ndeps ? dag_ver(g, di, dj) : nullptr, want, &s_ok)) break;
         DAG_DBG(1, 2);
         DAG_TRACE(t, 1);
         dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1);
@@ -387,27 +536,47 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         nodes[to].npred++;
     };
     // durations in microseconds as measured at N = 10 000 (bulk workgroups share a CU's matrix cores in pairs, the
-    // chain has its CU to itself); only their proportions matter
-    const float D_DIAG = 50.f, D_CHAIN_OP = 24.f, D_OP = 33.f, D_OVH = 5.f;
+    // chain team's members have their CUs to themselves); only their proportions matter
+    const float D_DIAG = 45.f, D_STRIP = 10.f, D_OP = 34.f, D_OVH = 5.f;
+    int prev_h5 = -1;
     for (int k = 0; k < nt; ++k) {
-        // the chain's three links of column step k: never ticketed (one dedicated workgroup runs them all), but part
-        // of the simulation, where they start the moment their inputs are there (ON_CHAIN)
-        const int d = add(DAG_CHAIN, k, k, k, k + 1, D_DIAG);
-        nodes[d].on_chain = true;
+        // the chain team's work of column step k: never ticketed, but part of the simulation, where each link starts
+        // the moment its inputs are there (on_chain)
+        auto chain = [&](int i, int j, float dur) {
+            const int v = add(DAG_CHAIN, i, j, k, k + 1, dur);
+            nodes[v].on_chain = true;
+            return v;
+        };
+        const int d = chain(k, k, D_DIAG);
         edge(last_writer[(size_t)k * nt + k], d);
         if (k + 1 < nt) {
-            const int b = add(DAG_CHAIN, k + 1, k, k, k + 1, D_CHAIN_OP);          // TRSM(k+1,k)
-            nodes[b].on_chain = true;
-            edge(d, b);
-            edge(last_writer[(size_t)(k + 1) * nt + k], b);
-            trsm[(size_t)(k + 1) * nt + k] = b;
-            const int c2 = add(DAG_CHAIN, k + 1, k + 1, k, k + 1, D_CHAIN_OP);     // UPD(k+1,k+1,k,k+1)
-            nodes[c2].on_chain = true;
-            edge(b, c2);
-            edge(last_writer[(size_t)(k + 1) * nt + (k + 1)], c2);
-            last_writer[(size_t)(k + 1) * nt + (k + 1)] = c2;
+            const int h1 = chain(k + 1, k, D_STRIP);                         // TRSM(k+1,k)
+            edge(d, h1);
+            edge(prev_h5, h1);                                               // the helpers work in sequence
+            edge(last_writer[(size_t)(k + 1) * nt + k], h1);
+            trsm[(size_t)(k + 1) * nt + k] = h1;
+            const int h2 = chain(k + 1, k + 1, D_STRIP);                     // UPD(k+1,k+1,k)
+            edge(h1, h2);
+            edge(last_writer[(size_t)(k + 1) * nt + (k + 1)], h2);
+            last_writer[(size_t)(k + 1) * nt + (k + 1)] = h2;
+            prev_h5 = h2;
+            if (k + 2 < nt) {
+                const int h3 = chain(k + 2, k, D_STRIP);                     // TRSM(k+2,k)
+                edge(h2, h3);
+                edge(last_writer[(size_t)(k + 2) * nt + k], h3);
+                trsm[(size_t)(k + 2) * nt + k] = h3;
+                const int h4 = chain(k + 2, k + 1, D_STRIP);                 // UPD(k+2,k+1,k)
+                edge(h3, h4);
+                edge(last_writer[(size_t)(k + 2) * nt + (k + 1)], h4);
+                last_writer[(size_t)(k + 2) * nt + (k + 1)] = h4;
+                const int h5 = chain(k + 2, k + 2, D_STRIP);                 // UPD(k+2,k+2,k)
+                edge(h4, h5);
+                edge(last_writer[(size_t)(k + 2) * nt + (k + 2)], h5);
+                last_writer[(size_t)(k + 2) * nt + (k + 2)] = h5;
+                prev_h5 = h5;
+            }
         }
-        for (int i = k + 2; i < nt; ++i) {
+        for (int i = k + 3; i < nt; ++i) {
             const int tr = add(DAG_TRSM, i, k, k, k + 1, D_OP + D_OVH);
             edge(d, tr);
             edge(last_writer[(size_t)i * nt + k], tr);
@@ -426,7 +595,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             const int kf = batched_until(j, W);
             if (k >= kf) {
                 for (int i = j; i < nt; ++i)
-                    if (!(i == k + 1 && j == k + 1)) upd(i, j, k, k + 1);    // single step ((k+1,k+1) is CHAIN(k)'s)
+                    if (i > k + 2) upd(i, j, k, k + 1);                      // single step (rows k+1, k+2 are the team's)
             } else if ((k + 1) % 4 == 0) {
                 for (int i = j; i < nt; ++i) upd(i, j, k - 3, k + 1);        // batch of four
             }
@@ -439,14 +608,15 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         for (int s : nodes[v].succ) b = std::max(b, nodes[s].prio);
         nodes[v].prio = b + nodes[v].dur;
     }
-    // list scheduling on `workers` identical workers
+    // list scheduling of the ticketed tasks on the workers left beside the team; chain links start the moment they
+    // are ready
     typedef std::pair<float, int> PI;
     std::priority_queue<PI> ready;                                           // max bottom level first
     std::priority_queue<PI, std::vector<PI>, std::greater<PI>> running;      // earliest finish first
     out.tasks.clear();
     out.tasks.reserve(n);
     float now = 0;
-    int freew = workers - 2, started = 0;                                    // the chain workgroup and its retired CU neighbour
+    int freew = workers - 2 * DAG_TEAM, started = 0;                         // the team and its retired CU neighbours
     auto release = [&](int v) {                                              // all inputs of v are there
         if (nodes[v].on_chain) {
             running.push(PI(now + nodes[v].dur, v));
@@ -483,7 +653,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
 template <typename T>
 int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
     const int nt = (int)(npad / NB);
-    static const int W = getenv("ALGP_DAG_WINDOW") ? atoi(getenv("ALGP_DAG_WINDOW")) : 4;
+    static const int W = std::max(2, getenv("ALGP_DAG_WINDOW") ? atoi(getenv("ALGP_DAG_WINDOW")) : 4);   // >= 2: the team owns rows k+1, k+2
     DagCache* dc = nullptr;
     for (auto& e : c->dag_cache)
         if (e.nt == nt) dc = &e;
@@ -508,7 +678,7 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
     }
     // per-launch state: tile versions, control words, per-block log-determinants (one zeroed block)
     const size_t nver = (size_t)nt * nt;
-    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + 4) + sizeof(double) * nt + 16), 16);
+    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt) + sizeof(double) * nt + 16), 16);
     ALGP_TRY(ensure(c, c->dag_state, state_bytes));
     ALGP_HIP(hipMemsetAsync(c->dag_state.p, 0, state_bytes, c->cur));
     DagArgs<T> g;
@@ -520,7 +690,8 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
     g.nt = nt;
     g.ld_blocks = (double*)c->dag_state.p;                     // doubles first (8-byte aligned)
     g.ctrl = (int*)((char*)c->dag_state.p + sizeof(double) * nt);
-    g.ver = g.ctrl + 4;
+    g.cnt = g.ctrl + (DAG_CTRL + 3) / 4 * 4;
+    g.ver = g.cnt + 5 * nt;
     g.info = info;
     const double flops = (double)npad * npad * npad / 3.0;
     {
