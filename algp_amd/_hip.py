@@ -22,7 +22,7 @@ KERNEL_RBF, KERNEL_MATERN15 = 0, 1
 CRIT_ENTROPY, CRIT_MUTUAL_INFORMATION = 0, 1
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_OOM, ERR_STATE, ERR_NO_DEVICE = range(7)
 PROF = dict(kmat=0, gemm_chol=1, gemm_trsm=2, potrf_diag=3, trsv=4, rows=5, score=6, gemm_other=7, cholesky=8, trsm=9,
-            gemm_chol_update=10)
+            gemm_chol_update=10, chol_dag=11)
 
 _c_ctx = C.c_void_p
 _i64p = C.POINTER(C.c_int64)
@@ -80,6 +80,7 @@ SIGNATURES = {
     'algp_prof_enable': (C.c_int, [_c_ctx, C.c_int]),
     'algp_prof_reset': (C.c_int, [_c_ctx]),
     'algp_prof_get': (C.c_int, [_c_ctx, C.c_int, _dblp, _dblp, _dblp, _i64p]),
+    'algp_cholesky_task_stats': (C.c_int, [_c_ctx, _dblp]),
 }
 
 _lib = None
@@ -417,6 +418,13 @@ class Context(object):
 
     def prof_reset(self):
         self._check(self.lib.algp_prof_reset(self.h))
+
+    def cholesky_task_stats(self):
+        """In-kernel accounting of the one-launch Cholesky since prof_reset (while profiling is enabled):
+        dict(update_us, update_steps, trsm_us, trsm_count), see include/algp_hip.h."""
+        out = (C.c_double * 4)()
+        self._check(self.lib.algp_cholesky_task_stats(self.h, out))
+        return dict(update_us=out[0], update_steps=out[1], trsm_us=out[2], trsm_count=out[3])
 
     def prof_get(self, klass):
         ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()

@@ -1289,7 +1289,7 @@ void algp_destroy(algp_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
-                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->dag_state, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->dag_state, &c->dag_stats, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
     dag_release(c);
@@ -1576,6 +1576,21 @@ int algp_prof_reset(algp_ctx* c) {
     hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (int i = 0; i < ALGP_PROF_COUNT; ++i) c->prof[i] = ProfSlot();
+    if (c->dag_stats.p) ALGP_HIP(hipMemset(c->dag_stats.p, 0, 64));
+    return ALGP_OK;
+}
+int algp_cholesky_task_stats(algp_ctx* c, double out[4]) {
+    CHECK_CTX(c);
+    if (!out) return fail(c, ALGP_ERR_BAD_ARG, "cholesky_task_stats: null output");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (c->dag_stats.p) {
+        ALGP_HIP(hipStreamSynchronize(c->stream));
+        ALGP_HIP(hipMemcpy(h, c->dag_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    out[0] = (double)h[0] * 0.01;                              // 100 MHz ticks -> microseconds
+    out[1] = (double)h[1];
+    out[2] = (double)h[2] * 0.01;
+    out[3] = (double)h[3];
     return ALGP_OK;
 }
 int algp_prof_get(algp_ctx* c, int klass, double* ms, double* flops, double* bytes, int64_t* launches) {

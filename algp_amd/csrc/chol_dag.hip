@@ -52,6 +52,8 @@ struct DagArgs {
     int* cnt;                                                  // per column step: strips published of the five team products
     double* ld_blocks;                                         // per diagonal block: sum(log pivots)
     int* info;
+    unsigned long long* stats;                                 // or null: [0] ticks (100 MHz) spent in UPD products, summed over
+                                                               // workgroups, [1] their K = 128 steps, [2] ticks in TRSM products, [3] their count
 };
 
 // Diagnostic builds only (tools/dag_test.hip): per-workgroup progress words the host can read while the launch runs.
@@ -441,6 +443,8 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     }
 
     // ---- everybody else draws tickets from the list ----
+    unsigned long long st_upd = 0, st_trsm = 0;
+    unsigned st_steps = 0, st_ntrsm = 0;
     for (;;) {
         if (tid < 64) {
             // a bulk workgroup that shares its CU with a team or pool member retires
@@ -477,12 +481,22 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         if (!dag_wait<T>(g, t, lane < ndeps ? dag_ver(g, di, dj) : nullptr, want, &s_ok)) break;
         DAG_DBG(1, 2);
         DAG_TRACE(t, 1);
+        const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
         dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1);
+        const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - tick0;
+        if (type == DAG_UPD) { st_upd += ticks; st_steps += (unsigned)(k1 - k0); }
+        else { st_trsm += ticks; ++st_ntrsm; }
         DAG_DBG(1, 3);
         DAG_TRACE(t, 2);
         dag_publish<T>(g, ti, tj, (type == DAG_UPD) ? k1 : tj + 1);
         DAG_DBG(1, 4);
         DAG_TRACE(t, 3);
+    }
+    if (g.stats && tid == 0) {
+        atomicAdd(g.stats + 0, st_upd);
+        atomicAdd(g.stats + 1, (unsigned long long)st_steps);
+        atomicAdd(g.stats + 2, st_trsm);
+        atomicAdd(g.stats + 3, (unsigned long long)st_ntrsm);
     }
     DAG_DBG(1, 5);
 }
@@ -693,9 +707,17 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
     g.cnt = g.ctrl + (DAG_CTRL + 3) / 4 * 4;
     g.ver = g.cnt + 5 * nt;
     g.info = info;
+    g.stats = nullptr;
+    if (c->prof_on) {                                          // in-kernel accounting only while profiling is enabled
+        if (!c->dag_stats.p) {
+            ALGP_TRY(ensure(c, c->dag_stats, 64));
+            ALGP_HIP(hipMemsetAsync(c->dag_stats.p, 0, 64, c->cur));
+        }
+        g.stats = (unsigned long long*)c->dag_stats.p;
+    }
     const double flops = (double)npad * npad * npad / 3.0;
     {
-        ProfScope ps(c, ALGP_PROF_GEMM_CHOL_UPDATE, flops, sizeof(T) * (double)npad * npad);
+        ProfScope ps(c, ALGP_PROF_CHOL_DAG, flops, sizeof(T) * (double)npad * npad);
         int grid = 2 * 256;
         if (grid > dc->ntasks) grid = dc->ntasks;
         hipLaunchKernelGGL(chol_dag_kernel<T>, dim3(grid), dim3(256), 0, c->cur, g);

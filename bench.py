@@ -6,9 +6,12 @@ One "step" = one planning step of the reference's agent at fixed hyper-parameter
   MI-score : V^T = B^T L^-T for all candidates (blocked TRSM on MFMA), posterior mean/variance,
              k = 4 greedy picks (arguments.py:22): utilities -> all-gather -> argmax -> rank-1 commit
 Workload (BASELINE.json configs[3] on ONE GPU; it fits: L 0.8 GB + V^T 8.2 GB fp64):
-  N = 10 000 train points (100 x 100 mixture-of-Gaussians field, utils.py:90-108),
-  M = 100 000 candidates PER GPU (weak scaling: rank r scores its own 100 000), D = 2, fp64,
-  entropy criterion (the reference's effective default, agent.py:125), sigma_s = 0.1, sigma_m = 1.
+  N = 10 000 train points (100 x 100 mixture-of-Gaussians field, utils.py:90-108), D = 2, fp64,
+  M = 100 000 candidates -- PER GPU with --scaling weak (default: rank r scores its own 100 000),
+  IN TOTAL with --scaling strong (BASELINE config 4: the 100 000 are split over the ranks);
+  information-gain criterion = entropy (the reference's effective default, agent.py:125; the MI criterion
+  needs diag(C_rest^-1) over the whole pool, 2 x 110 000^2 x 8 B = 190 GB of scratch at this size and does not
+  shard: it is timed at a single-GPU size in `extra.mi_criterion`), sigma_s = 0.1, sigma_m = 1.
 Inputs (coordinates, targets, noise) are resident in HBM before the timed region.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
@@ -33,6 +36,7 @@ sys.path.insert(0, REPO)
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix (= vector) peak, SURVEY.md section 8(d)
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip-level parameters
 HBM_PEAK_GBS = 8000.0
+CUS = 256
 
 
 def mog_field(R, C, rng, k=5, min_var=10, max_var=100):
@@ -47,84 +51,246 @@ def mog_field(R, C, rng, k=5, min_var=10, max_var=100):
     return grid, y
 
 
+def candidate_lattice(n, R, C, shift=0):
+    """n candidate sites on an offset lattice over the R x C field, none coinciding with a grid site."""
+    cw = int(np.ceil(np.sqrt(n * C / R)))
+    ch = int(np.ceil(n / cw))
+    ii, jj = np.meshgrid(np.arange(ch), np.arange(cw), indexing='ij')
+    c = np.vstack([(ii.ravel() + 0.37 + 0.011 * shift) * (R / ch), (jj.ravel() + 0.41 + 0.007 * shift) * (C / cw)]).T
+    return c[:n]
+
+
 def build_workload(args, world):
     rng = np.random.RandomState(1)                       # arguments.py:33 default seed
     R = int(round(np.sqrt(args.train)))
-    grid, field = mog_field(R, args.train // R, rng)
+    C = args.train // R
+    grid, field = mog_field(R, C, rng)
     N = len(grid)
     static_std, mobile_std = 0.1, 1.0
     # half the sampled sites carry static readings, half mobile ones (fusion rule agent.py:100-109)
     is_static = rng.uniform(size=N) < 0.5
     var = np.where(is_static, static_std ** 2, mobile_std ** 2)
     y = np.maximum(field + rng.standard_normal(N) * np.sqrt(var), 0.0)     # env.py:110-112
-    # candidates: per rank an offset lattice over the same field, none coinciding with a train site
-    per = args.cand
-    cw = int(np.ceil(np.sqrt(per * (args.train // R) / R)))
-    ch = int(np.ceil(per / cw))
-    cands = []
-    for r in range(world):
-        ii, jj = np.meshgrid(np.arange(ch), np.arange(cw), indexing='ij')
-        c = np.vstack([(ii.ravel() + 0.37 + 0.011 * r) * (R / ch), (jj.ravel() + 0.41 + 0.007 * r) * ((args.train // R) / cw)]).T
-        cands.append(c[:per])
+    if args.scaling == 'weak':
+        # per rank an offset lattice of args.cand sites over the same field
+        cands = [candidate_lattice(args.cand, R, C, r) for r in range(world)]
+        counts = [args.cand] * world
+    else:
+        # ONE list of args.cand sites, cut into contiguous shards (the partition ShardedGreedy uses)
+        from algp_amd.sharded import partition
+        allc = candidate_lattice(args.cand, R, C, 0)
+        parts = partition(args.cand, world)
+        cands = [allc[a:b] for a, b in parts]
+        counts = [b - a for a, b in parts]
     pool = np.vstack([grid] + cands)
-    return dict(pool=pool, N=N, y=y, var=var, per=per, static_std=static_std, mobile_std=mobile_std)
+    return dict(pool=pool, N=N, y=y, var=var, counts=counts, static_std=static_std, mobile_std=mobile_std, R=R, C=C)
+
+
+def blas_info():
+    try:
+        cfg = np.show_config(mode='dicts')
+        b = cfg.get('Build Dependencies', {}).get('blas', {})
+        name = '%s %s' % (b.get('name', '?'), b.get('version', ''))
+    except Exception:
+        name = 'unknown'
+    threads = os.environ.get('OPENBLAS_NUM_THREADS') or os.environ.get('OMP_NUM_THREADS') or os.environ.get('MKL_NUM_THREADS')
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    return name.strip(), (int(threads) if threads else cores), cores
 
 
 def cpu_baseline(w, hyp_vals, args):
     """Reference-faithful CPU path (oracle 'port') on a bounded sample of the same workload:
-    full-size fit (fp32 kernel + np.linalg.inv, utils.py:296-300) on a sub-sampled train set when
-    the full one would take minutes, plus `ncand` per-candidate slogdets (agent.py:328-329);
-    extrapolated linearly in candidates x picks and cubically in N (stated in `sample`)."""
+    fit (fp32 kernel + np.linalg.inv, utils.py:296-300) on a sub-sampled train set plus `ncand` per-candidate
+    slogdets (agent.py:328-329); one warm-up, then the median of 3 runs; extrapolated linearly in
+    candidates x picks and cubically in N (stated in `sample`)."""
     from oracle import gp_oracle as O
     hyp = O.Hypers(np.log(hyp_vals['ls']), np.log(hyp_vals['os']), np.log(hyp_vals['noise']))
-    N = w['N']
+    N, M = w['N'], w['counts'][0]
     Ns = min(N, args.cpu_train)
     sel = np.sort(np.random.RandomState(0).permutation(N)[:Ns])
     X = w['pool'][:N][sel]
     var = w['var'][sel]
     ncand = 2
-    t0 = time.time()
-    cov_aa = O.cov_mat_ref(hyp, X, None, var, True, dtype=np.float32)
-    inv = np.linalg.inv(cov_aa)
-    mat1 = inv @ (w['y'][sel] - w['y'][sel].mean()).astype(np.float32)
-    t_fit = time.time() - t0
-    t0 = time.time()
     xc = w['pool'][N:N + ncand]
-    for i in range(ncand):
-        Xa = np.vstack([X, xc[i:i + 1]])
-        cov_a = O.cov_mat_ref(hyp, Xa, None, None, True, dtype=np.float32) + np.diag(np.r_[var, 0.01])
-        O.entropy_from_cov_ref(cov_a)
-    t_cand = (time.time() - t0) / ncand
-    scale = (N / Ns) ** 3
-    k = 4
-    t_step = scale * (t_fit + k * w['per'] * t_cand)
-    # efficient CPU form (Cholesky + identities), sampled candidates, for an honest second figure
+
+    def faithful():
+        t0 = time.time()
+        cov_aa = O.cov_mat_ref(hyp, X, None, var, True, dtype=np.float32)
+        inv = np.linalg.inv(cov_aa)
+        inv @ (w['y'][sel] - w['y'][sel].mean()).astype(np.float32)
+        t_fit = time.time() - t0
+        t0 = time.time()
+        for i in range(ncand):
+            Xa = np.vstack([X, xc[i:i + 1]])
+            cov_a = O.cov_mat_ref(hyp, Xa, None, None, True, dtype=np.float32) + np.diag(np.r_[var, 0.01])
+            O.entropy_from_cov_ref(cov_a)
+        return t_fit, (time.time() - t0) / ncand
+
     from scipy.linalg import solve_triangular
-    t0 = time.time()
-    S = O.kernel_matrix(hyp, X) + np.diag(var) + hyp.noise * np.eye(Ns)
-    L = np.linalg.cholesky(S)
     ms = 2048
-    B = O.kernel_matrix(hyp, X, w['pool'][N:N + ms])
-    V = solve_triangular(L, B, lower=True)
-    pv = hyp.outputscale + hyp.noise - np.sum(V * V, axis=0)
-    assert np.all(pv > 0)
-    t_eff = time.time() - t0
-    # the O(N^2 M) triangular solve dominates at these sizes: scale by (N/Ns)^2 * (M/ms)
-    t_eff_step = (N / Ns) ** 2 * (w['per'] / ms) * t_eff
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count()
+
+    def efficient():
+        t0 = time.time()
+        S = O.kernel_matrix(hyp, X) + np.diag(var) + hyp.noise * np.eye(Ns)
+        L = np.linalg.cholesky(S)
+        B = O.kernel_matrix(hyp, X, w['pool'][N:N + ms])
+        V = solve_triangular(L, B, lower=True)
+        pv = hyp.outputscale + hyp.noise - np.sum(V * V, axis=0)
+        assert np.all(pv > 0)
+        return time.time() - t0
+
+    faithful()                                                    # warm-up (BLAS thread pool, page faults)
+    runs = [faithful() for _ in range(3)]
+    t_fit = float(np.median([r[0] for r in runs]))
+    t_cand = float(np.median([r[1] for r in runs]))
+    efficient()
+    t_eff = float(np.median([efficient() for _ in range(3)]))
+    k = args.picks
+    t_step = (N / Ns) ** 3 * (t_fit + k * M * t_cand)
+    # the O(N^2 M) triangular solve dominates the efficient form at these sizes: scale by (N/Ns)^2 * (M/ms)
+    t_eff_step = (N / Ns) ** 2 * (M / ms) * t_eff
+    blas, threads, cores = blas_info()
     return {
-        'value': w['per'] / t_step, 'unit': 'candidates/s', 'cores': cores, 'kind': 'port',
+        'value': M / t_step, 'unit': 'candidates/s', 'cores': cores, 'kind': 'port',
+        'blas': blas, 'blas_threads': threads, 'os_cpu_count': os.cpu_count(),
         'sample': 'reference-faithful oracle (fp32 kernel, np.linalg.inv, one slogdet per candidate) at '
-                  'N=%d of %d train, %d of %d candidates, 1 of %d picks; %.1fs measured; extrapolated x(N/Ns)^3, '
-                  'linear in candidates x picks' % (Ns, N, ncand, w['per'], k, t_fit + ncand * t_cand),
+                  'N=%d of %d train, %d of %d candidates, 1 of %d picks; 1 warm-up + median of 3 runs (fit %.2fs, %.2fs per '
+                  'candidate); extrapolated x(N/Ns)^3, linear in candidates x picks' % (Ns, N, ncand, M, k, t_fit, t_cand),
         'ms_per_step_extrapolated': 1e3 * t_step,
-        'efficient_cpu_candidates_per_s': w['per'] / t_eff_step,
-        'efficient_cpu_sample': 'numpy/scipy Cholesky + triangular solve + variance, N=%d, %d candidates, %.1fs; '
+        'efficient_cpu_candidates_per_s': M / t_eff_step,
+        'efficient_cpu_sample': 'numpy/scipy Cholesky + triangular solve + variance, N=%d, %d candidates, median of 3: %.2fs; '
                                 'extrapolated x(N/Ns)^2 x M/%d' % (Ns, ms, t_eff, ms),
     }
+
+
+def extra_c3(_hip, device):
+    """BASELINE config 3: 10 000-point field, fp32 -- Cholesky + posterior on 10 000 held-out sites."""
+    rng = np.random.RandomState(3)
+    grid, field = mog_field(100, 100, rng)
+    N = len(grid)
+    test = candidate_lattice(10000, 100, 100, 1)
+    c = _hip.Context(np.float32, device=device)
+    c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    c.set_pool(np.vstack([grid, test]))
+    c.set_train(np.arange(N), field + 0.1 * rng.standard_normal(N), np.full(N, 0.01))
+    c.set_candidates(np.arange(N, N + len(test)), prior_includes_noise=False)
+    c.factorize()
+    c.solve_candidates()
+    c.prof_enable(True)
+    c.prof_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c.factorize()
+        c.solve_candidates()
+        mu, pv = c.posterior()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    ch, dag, tr = c.prof_get('cholesky'), c.prof_get('chol_dag'), c.prof_get('trsm')
+    st = c.cholesky_task_stats()
+    c.prof_enable(False)
+    c.close()
+    chol_ms = ch['ms'] / reps
+    dag_ms = dag['ms'] / reps
+    out = {'workload': 'C3: 10 000-point field, fp32: fit (kernel build + Cholesky + alpha) + posterior on 10 000 sites',
+           'dtype': 'f32', 'ms_per_step': wall, 'fit_ms': chol_ms,
+           'cholesky_kernel_ms': dag_ms, 'cholesky_tflops': N ** 3 / 3.0 / (dag_ms * 1e-3) / 1e12 if dag_ms > 0 else None,
+           'posterior_solve_ms': tr['ms'] / reps,
+           'roofline': {'bound': 'mfma', 'kernel': 'chol_dag_kernel<float>', 'unit': 'TFLOP/s', 'peak': FP32_MATRIX_PEAK_TFLOPS}}
+    if dag_ms > 0:
+        out['roofline']['achieved'] = N ** 3 / 3.0 / (dag_ms * 1e-3) / 1e12
+        out['roofline']['frac'] = out['roofline']['achieved'] / FP32_MATRIX_PEAK_TFLOPS
+    if st['update_us'] > 0:
+        out['cholesky_update_tflops_while_computing'] = 2 * 128.0 ** 3 * st['update_steps'] / (st['update_us'] * 1e-6 / (2 * CUS)) / 1e12
+    return out
+
+
+def extra_c5(_hip, device, picks):
+    """BASELINE config 5 on one GPU: 50 000-point field fp64, 100 000 candidates: one from-scratch planning step, then 10
+    steps of the active-learning loop (each appends the 4 picks + 28 mobile sites) through the incremental factor."""
+    rng = np.random.RandomState(5)
+    R, C = 250, 200
+    grid, field = mog_field(R, C, rng)
+    N0, M = len(grid), 100000
+    cand = candidate_lattice(M, R, C, 2) + 0.03 * rng.standard_normal((M, 2))
+    pool = np.vstack([grid, cand])
+    c = _hip.Context(np.float64, device=device)
+    c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    c.set_pool(pool)
+    idx = np.arange(N0)
+    var = np.where(rng.uniform(size=N0) < 0.5, 0.01, 1.0)
+    y = np.maximum(field + rng.standard_normal(N0) * np.sqrt(var), 0.0)
+    static = np.zeros(len(pool), bool)
+    static[:N0] = var == 0.01
+    cidx = np.arange(N0, N0 + M)
+    times, chol_ms = [], None
+    for s in range(11):
+        inc = s > 0
+        if s == 0:
+            c.prof_enable(True)
+            c.prof_reset()
+        t0 = time.perf_counter()
+        c.set_train(idx, y, var)
+        c.factorize(incremental=inc)
+        c.set_candidates(cidx, prior_includes_noise=True)
+        c.solve_candidates(incremental=inc, alive=~static[cidx])
+        pk = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, picks)
+        c.sync()
+        times.append((time.perf_counter() - t0) * 1e3)
+        if s == 0:
+            chol_ms = c.prof_get('cholesky')['ms']
+            trsm = c.prof_get('trsm')
+            gt = c.prof_get('gemm_trsm')
+            c.prof_enable(False)
+        static[pk] = True
+        mob = cidx[rng.permutation(M)[:28]]
+        mob = mob[~np.isin(mob, idx) & ~np.isin(mob, pk)]
+        idx = np.r_[idx, pk, mob]
+        var = np.r_[var, np.full(len(pk), 0.01), np.full(len(mob), 1.0)]
+        y = np.r_[y, rng.uniform(0, 1, len(pk) + len(mob))]
+    dev_gb = c.device_bytes() / 1e9
+    c.close()
+    ctf = N0 ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12
+    ttf = float(N0) ** 2 * M / (trsm['ms'] * 1e-3) / 1e12
+    return {'workload': 'C5 on one GPU: 50 000-point field, fp64, 100 000 candidates, %d picks/step' % picks, 'dtype': 'f64',
+            'from_scratch_step_ms': times[0], 'incremental_step_ms_median': float(np.median(times[1:])),
+            'incremental_step_ms_max': float(np.max(times[1:])), 'incremental_steps': len(times) - 1,
+            'fit_ms': chol_ms, 'cholesky_tflops': ctf, 'device_gb': dev_gb,
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<double> (candidate TRSM, N^2 M / wall time of the solve)',
+                         'achieved': ttf, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ttf / FP64_MATRIX_PEAK_TFLOPS},
+            'cholesky_roofline': {'achieved': ctf, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'frac': ctf / FP64_MATRIX_PEAK_TFLOPS,
+                                  'note': 'N^3/3 over the whole fit (kernel build + factorisation + z); launch sequence of '
+                                          'potrf.hip (the one-launch task list is used up to N = 24 576)'}}
+
+
+def extra_mi(_hip, device):
+    """The mutual-information criterion (agent.py:330-339) at a single-GPU size: pool 5 000 sites, 1 000 sampled."""
+    rng = np.random.RandomState(7)
+    grid, field = mog_field(50, 100, rng)
+    n = len(grid)
+    perm = rng.permutation(n)
+    A = np.sort(perm[:1000])
+    cand = np.sort(perm[1000:])
+    c = _hip.Context(np.float64, device=device)
+    c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    c.set_pool(grid)
+    c.set_train(A, field[A], np.full(len(A), 0.01))
+    c.factorize()
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    c.greedy(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0, 1)                           # warm-up (scratch allocation)
+    c.solve_candidates()
+    c.sync()
+    t0 = time.perf_counter()
+    pk = c.greedy(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0, 1)
+    c.sync()
+    ms = (time.perf_counter() - t0) * 1e3
+    c.close()
+    return {'workload': 'MI criterion: pool n=5 000, |A|=1 000 sampled, 4 000 candidates, one pick (two pool-wide O(n^3) '
+                        'factorisations + inverse diagonals per pick)', 'dtype': 'f64', 'ms_per_pick': ms,
+            'candidates_per_s': len(cand) / (ms * 1e-3), 'pick': int(pk[0])}
 
 
 def main():
@@ -133,15 +299,17 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--train', type=int, default=10000)
-    ap.add_argument('--cand', type=int, default=100000, help='candidates per GPU')
+    ap.add_argument('--cand', type=int, default=100000, help='candidates per GPU (weak) or in total (strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--picks', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the C3 / C5 / MI legs (they run after the timed region)')
     ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed/RCCL path even with one rank')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo only for rehearsing several ranks on ONE card (RCCL refuses duplicate devices)')
-    ap.add_argument('--cpu-train', type=int, default=8000)
-    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'traffic.json'))
+    ap.add_argument('--cpu-train', type=int, default=6000)
+    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r02_traffic_pmc.json'))
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that write to fd 1 (RCCL prints a version banner
@@ -180,10 +348,12 @@ def main():
     ctx = _hip.Context(dt, device=local_rank)
     ctx.set_hypers(np.log(hyp_vals['ls']), np.log(hyp_vals['os']), np.log(hyp_vals['noise']))
     ctx.set_pool(w['pool'])
-    N, per = w['N'], w['per']
+    N = w['N']
+    offs = np.concatenate([[0], np.cumsum(w['counts'])])
+    total_c = int(offs[-1])
     ctx.set_train(np.arange(N), w['y'], w['var'])
-    all_cand = np.arange(N, N + per * world)
-    mine = all_cand[rank * per:(rank + 1) * per]
+    all_cand = np.arange(N, N + total_c)
+    mine = all_cand[offs[rank]:offs[rank + 1]]
     ctx.set_candidates(mine, prior_includes_noise=True)
     comm = TorchComm(torch.device('cuda', local_rank)) if dist is not None else LocalComm()
 
@@ -205,71 +375,128 @@ def main():
             picks, _ = sg.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks)
         picks_log.append([int(p) for p in picks])
 
+    def timed(nsteps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(args.warmup):
         step()
+    # the timed region: K steps with the library's HIP-event profiling on (the roofline figures below come from these
+    # very launches); the same K steps are then repeated without the ~600 event pairs per step
     ctx.prof_enable(True)
     ctx.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps)
     prof = {k: ctx.prof_get(k) for k in _hip.PROF}
+    chol_stats = ctx.cholesky_task_stats()
     ctx.prof_enable(False)
+    elapsed_unprof = timed(args.steps)
 
     if rank == 0:
-        ms_step = 1e3 * elapsed / args.steps
-        total_c = per * world
+        K = args.steps
+        ms_step = 1e3 * elapsed / K
         peak = FP64_MATRIX_PEAK_TFLOPS if args.dtype == 'f64' else FP32_MATRIX_PEAK_TFLOPS
+        es = 8 if args.dtype == 'f64' else 4
+        Mloc = int(w['counts'][0])
         g = prof['gemm_trsm']
-        span = prof['trsm']                                       # wall time of the solves (two overlapped streams)
-        ach = g['flops'] / (span['ms'] * 1e-3) / 1e12 if span['ms'] > 0 else 0.0
+        span = prof['trsm']                                       # wall time of the solves (row chunks overlap on 3 streams)
+        alg_flops_step = float(N) ** 2 * Mloc                     # N^2 flop per candidate
+        ach = alg_flops_step * K / (span['ms'] * 1e-3) / 1e12 if span['ms'] > 0 else 0.0
+        ach_padded = g['flops'] / (span['ms'] * 1e-3) / 1e12 if span['ms'] > 0 else 0.0
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
                 traffic = json.load(open(args.traffic_json)).get('gemm_nt_%s_bytes_per_launch' % args.dtype)
             except Exception:
                 traffic = None
-        gc = prof['gemm_chol']
-        gu = prof['gemm_chol_update']
-        gu_tf = gu['flops'] / (gu['ms'] * 1e-3) / 1e12 if gu['ms'] > 0 else 0.0
-        chol_ms = prof['cholesky']['ms'] / args.steps            # wall time of the factorisation (two overlapped streams)
-        chol_tf = (N ** 3 / 3.0) / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
+        dag = prof['chol_dag']
+        fit_ms = prof['cholesky']['ms'] / K                       # wall time of the fit (kernel build, factorisation, z)
+        dag_ms = dag['ms'] / K if dag['launches'] else None       # the factorisation proper (one launch)
+        chol_tf = (N ** 3 / 3.0) / (fit_ms * 1e-3) / 1e12 if fit_ms > 0 else 0.0
+        upd_tf = None
+        if chol_stats['update_us'] > 0:
+            # rank-k update ("panel update") tasks inside the one-launch factorisation: flops / time the workgroups spent in
+            # them; two workgroups share a CU, so the chip-level rate while they compute is over time / 2 / CUs
+            upd_tf = 2 * 128.0 ** 3 * chol_stats['update_steps'] / (chol_stats['update_us'] * 1e-6 / (2 * CUS)) / 1e12
+        stage = {k: v['ms'] / K for k, v in prof.items()}
+        # per-stage split of one step (ms): what is replicated on every rank vs what shards with the candidates
+        replicated = fit_ms
+        sharded_ms = max(ms_step - replicated, 0.0)
+        proj = {}
+        for n in (1, 2, 4, 8):
+            proj[str(n)] = {'ms_per_step': replicated + sharded_ms / n,
+                            'speedup_vs_1': ms_step / (replicated + sharded_ms / n),
+                            'scoring_only_speedup_vs_1': float(n)}
         out = {
             'metric': 'GP-fit+MI-score throughput (N train x M candidates)',
-            'value': total_c / (elapsed / args.steps),
+            'value': total_c / (elapsed / K),
             'unit': 'candidates/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup,
             'ms_per_step': ms_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step_unprofiled': 1e3 * elapsed_unprof / K,
+            'value_unprofiled': total_c / (elapsed_unprof / K),
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': '%d-point MoG field (train) x %d candidates/GPU, %d greedy picks, entropy criterion, D=2'
-                                   % (N, per, args.picks),
-                       'n_train': N, 'candidates_per_gpu': per, 'candidates_total': total_c,
+            'config': {'workload': '%d-point MoG field (train) x %d candidates %s, %d greedy picks, entropy criterion, D=2'
+                                   % (N, args.cand, 'per GPU' if args.scaling == 'weak' else 'in total', args.picks),
+                       'criterion': 'entropy (agent.py:125 default); the MI criterion (agent.py:330-339) needs pool-wide inverse '
+                                    'diagonals -- 190 GB of scratch at this size, not shardable -- and is timed in extra.mi_criterion',
+                       'n_train': N, 'candidates_per_gpu': Mloc, 'candidates_total': total_c,
                        'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + position)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<%s> (candidate TRSM)' % ('double' if args.dtype == 'f64' else 'float'),
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                         'traffic': traffic, 'launches': g['launches'], 'avg_launch_ms': g['ms'] / max(1, g['launches']),
+                         'traffic': traffic,
+                         'algorithmic_flops_per_step': alg_flops_step,
+                         'algorithmic_flops_per_launch': alg_flops_step * K / max(1, g['launches']),
+                         'launches': g['launches'], 'avg_launch_ms': g['ms'] / max(1, g['launches']),
                          'wall_ms_all_launches': span['ms'], 'sum_launch_ms': g['ms'],
-                         'note': 'launches of the two row halves overlap on two streams: achieved = flops / wall time of the solves',
-                         'flops_per_launch': g['flops'] / max(1, g['launches']),
-                         # the same kernel symbol also serves the factorisation: this is the figure rocprofv3 --stats
-                         # reports for the symbol (all its launches), for the cross-check against profiles/
-                         'symbol_launches': g['launches'] + gc['launches'] + gu['launches'],
-                         'symbol_avg_launch_ms': (g['ms'] + gc['ms'] + gu['ms']) / max(1, g['launches'] + gc['launches'] + gu['launches'])},
-            'cholesky_tflops': chol_tf, 'cholesky_ms': chol_ms,
-            'cholesky_gemm_tflops': (gc['flops'] + gu['flops']) / ((gc['ms'] + gu['ms']) * 1e-3) / 1e12 if gc['ms'] + gu['ms'] > 0 else 0.0,
-            # the factorisation's dense rank-512 trailing ("panel") updates on MFMA, HIP-event time of those launches
-            'cholesky_panel_update': {'achieved': gu_tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': gu_tf / peak,
-                                      'launches': gu['launches'], 'ms_per_step': gu['ms'] / args.steps},
-            'stage_ms_per_step': {k: v['ms'] / args.steps for k, v in prof.items()},
+                         'achieved_padded': ach_padded, 'padded_flops_per_step': g['flops'] / K,
+                         'note': 'achieved = N^2 M flop (SURVEY 8d) / wall time of the solve; the launches of the 3 row chunks '
+                                 'overlap on 3 streams, so sum_launch_ms > wall_ms_all_launches and avg_launch_ms (what rocprofv3 '
+                                 '--stats reports per launch) is not a denominator by itself; achieved_padded counts the '
+                                 'flops actually executed (128-padding + full-square diagonal-block products)'},
+            'cholesky': {'fit_ms': fit_ms, 'tflops_n3_over_3_per_fit_ms': chol_tf, 'kernel': 'chol_dag_kernel (one launch)',
+                         'kernel_ms': dag_ms,
+                         'kernel_tflops': (N ** 3 / 3.0) / (dag_ms * 1e-3) / 1e12 if dag_ms else None,
+                         'frac_of_peak': ((N ** 3 / 3.0) / (dag_ms * 1e-3) / 1e12 / peak) if dag_ms else None,
+                         'panel_update': {'achieved_while_computing': upd_tf, 'peak': peak, 'unit': 'TFLOP/s',
+                                          'frac': upd_tf / peak if upd_tf else None,
+                                          'update_task_us_summed_over_workgroups': chol_stats['update_us'] / K,
+                                          'update_k128_steps': chol_stats['update_steps'] / K,
+                                          'note': 'rank-k update tile tasks of the one-launch factorisation: 2*128^3 flop per K=128 step / '
+                                                  '(time inside the tasks / 2 workgroups per CU / 256 CUs), in-kernel 100 MHz stamps'}},
+            'cholesky_tflops': chol_tf, 'cholesky_ms': fit_ms,
+            'stage_ms_per_step': stage,
+            'throughput': {'with_factorisation_candidates_per_s': total_c / (elapsed / K),
+                           'scoring_only_candidates_per_s': total_c / (sharded_ms * 1e-3) if sharded_ms > 0 else None,
+                           'replicated_fit_ms': replicated, 'sharded_scoring_ms': sharded_ms},
+            'strong_projection': {'note': 'projection from this run\'s stage split, NOT measured: every rank repeats the fit '
+                                          '(replicated_fit_ms), the candidate work divides by the number of ranks',
+                                  'by_gpus': proj},
             'picks_last_step': picks_log[-1],
         }
+        extras = {}
+        if world == 1 and not args.no_extras:
+            ctx.close()
+            ctx = None
+            for name, fn in (('c3_fp32_10k', lambda: extra_c3(_hip, local_rank)),
+                             ('c5_fp64_50k', lambda: extra_c5(_hip, local_rank, args.picks)),
+                             ('mi_criterion', lambda: extra_mi(_hip, local_rank))):
+                t0 = time.perf_counter()
+                try:
+                    extras[name] = fn()
+                except Exception as e:                         # a failed extra must not cost the headline line
+                    extras[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+                extras[name]['leg_wall_s'] = time.perf_counter() - t0
+        out['extra'] = extras
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w, hyp_vals, args)
         else:
@@ -279,7 +506,8 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
         os.dup2(2, 1)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -60,7 +60,8 @@ enum {
     ALGP_PROF_TRSM = 9,        /* wall time of whole candidate solves (two overlapped streams)        */
     ALGP_PROF_GEMM_CHOL_UPDATE = 10, /* the Cholesky's K=512 trailing (rank-512) updates, a subset of GEMM_CHOL's work
                                       * counted here instead: the "dense panel update" of the blocked factorisation */
-    ALGP_PROF_COUNT = 11
+    ALGP_PROF_CHOL_DAG = 11,   /* the Cholesky as one dependency-driven launch (chol_dag.hip): the whole factorisation */
+    ALGP_PROF_COUNT = 12
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
@@ -221,6 +222,12 @@ int algp_prof_enable(algp_ctx* ctx, int on);
 int algp_prof_reset(algp_ctx* ctx);
 int algp_prof_get(algp_ctx* ctx, int klass, double* ms, double* flops, double* bytes,
                   int64_t* launches);
+/* In-kernel accounting of the one-launch Cholesky since the last algp_prof_reset (collected only while profiling is
+ * enabled): out[0] = microseconds spent inside the rank-k update products ("panel update", reference: the LU inside
+ * np.linalg.inv / slogdet, utils.py:193, 300), summed over workgroups; out[1] = their K = 128 steps (2 * 128^3 flop
+ * each); out[2], out[3] = the same for the triangular-solve tile products (microseconds, count). Two workgroups
+ * share a CU, so the update rate while computing is 2 * 128^3 * out[1] / (out[0] / 2 / CUs) flop/s. */
+int algp_cholesky_task_stats(algp_ctx* ctx, double out[4]);
 
 #ifdef __cplusplus
 }
