@@ -133,6 +133,8 @@ class Context(object):
             raise AlgpError(rc, 'algp_create failed')
         self.h = h
         self.device = int(device)
+        self.pool_generation = 0            # counts pool loads: owners of derived state compare it (Agent._load_pool)
+        self._pool_owner = None
 
     def close(self):
         if getattr(self, 'h', None):
@@ -177,15 +179,25 @@ class Context(object):
         self._check(self.lib.algp_set_hypers(self.h, int(kernel), len(ls), ls.ctypes.data_as(_dblp),
                                              float(log_outputscale), float(log_noise)))
 
+    def _check_width(self, x, what):
+        """The C side reads n * D values: a wrong-width array would be over-read or silently reinterpreted."""
+        D = getattr(self, 'D', None)
+        if D is None:
+            raise ValueError('%s: call set_hypers first (it fixes the input dimension)' % what)
+        if x.ndim != 2 or x.shape[1] != D:
+            raise ValueError('%s: expected coordinates of shape (n, %d), got %s' % (what, D, tuple(x.shape)))
+
     def kernel_matrix(self, x1, x2=None, diag_add=None, add_likelihood_var=False):
         x1 = self._arr(x1)
         x1 = x1.reshape(len(x1), -1)
+        self._check_width(x1, 'kernel_matrix x1')
         n1 = x1.shape[0]
         if x2 is None:
             n2, x2p = n1, None
         else:
             x2 = self._arr(x2)
             x2 = x2.reshape(len(x2), -1)
+            self._check_width(x2, 'kernel_matrix x2')
             n2, x2p = x2.shape[0], _ptr(x2)
         d = None if diag_add is None else self._arr(diag_add, (n1,))
         out = np.empty((n1, n2), dtype=self.dtype)
@@ -197,7 +209,10 @@ class Context(object):
     def set_pool(self, x):
         x = self._arr(x)
         x = x.reshape(len(x), -1)
+        self._check_width(x, 'set_pool')
         self.n_pool = x.shape[0]
+        self.pool_generation += 1
+        self._pool_owner = None
         self._check(self.lib.algp_set_pool(self.h, _ptr(x), x.shape[0]))
 
     def set_pool_cov(self, cov):
@@ -205,6 +220,8 @@ class Context(object):
         if cov.ndim != 2 or cov.shape[0] != cov.shape[1]:
             raise ValueError('cov must be square')
         self.n_pool = cov.shape[0]
+        self.pool_generation += 1
+        self._pool_owner = None
         self._check(self.lib.algp_set_pool_cov(self.h, _ptr(cov), cov.shape[0]))
 
     def set_train(self, idx, y, var=None):

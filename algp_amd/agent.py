@@ -196,13 +196,17 @@ class Agent(object):
         c = self.gp.ctx
         changed = self.gp.sync_hypers()
         key = ('cov', id(self._cov_matrix)) if self._cov_matrix_user else ('x', id(self.env.X))
-        if changed or key != self._pool_key or getattr(c, '_pool_owner', None) is not self:
+        # the device pool is this agent's only while nobody else has loaded one into the context since
+        # (GPR.predict, GPR.fit, utils.predictive_distribution all do): Context counts its pool loads
+        if (changed or key != self._pool_key or getattr(c, '_pool_owner', None) is not self
+                or c.pool_generation != getattr(self, '_pool_generation', -1)):
             if self._cov_matrix_user:
                 c.set_pool_cov(self._cov_matrix)
             else:
                 c.set_pool(self.env.X)
             self._pool_key = key
             c._pool_owner = self
+            self._pool_generation = c.pool_generation
         return c
 
     # ---- planning steps ---------------------------------------------------------------------------
@@ -258,6 +262,7 @@ class Agent(object):
         g = self.gp.ctx
         shared = False
         if (len(A) and self._pool_key == ('x', id(self.env.X)) and getattr(g, '_pool_owner', None) is self
+                and g.pool_generation == getattr(self, '_pool_generation', -1)
                 and not self.gp.sync_hypers() and getattr(g, 'M', 0) == n):
             try:
                 if rows:
@@ -557,17 +562,38 @@ class Agent(object):
         return {'mean': mu, 'error': errors, 'mi': mis, 'mean_var': mean_vars}
 
     def prediction_vs_distance(self, test_every, num_runs):
+        """Posterior on the held-out set after the first r * test_every collected samples, r = 1..num_runs
+        (agent.py:497-518).  The reference runs a from-scratch predictive_distribution per prefix; here the collected
+        samples are the rows of ONE context in collection order, so every prefix extends the previous factor
+        (algp_factorize_update) and only the new columns of V^T are solved (algp_solve_candidates_update).  A site
+        measured twice is two rows with independent likelihood noise, as in the reference's cov_aa (utils.py:296)."""
         errors, mis, mean_vars, mu = [], [], [], None
-        for r in range(1, num_runs + 1):
-            count = r * test_every
-            inds = np.array(self.collected['ind'][:count])
-            ok = inds != -1
-            x = self.env.X[inds[ok].astype(int)]
-            var = np.array(self.collected['std'])[:count][ok].astype(float) ** 2
-            y = np.array(self.collected['y'])[:count][ok].astype(float)
-            self._pool_key = None
-            mu, cov, mi = predictive_distribution(self.gp, x, y, self.env.test_X, var, return_mi=True, return_cov=True)
-            errors.append(compute_mae(self.env.test_Y, mu))
-            mis.append(mi)
-            mean_vars.append(np.diag(cov).mean())
+        inds = np.array(self.collected['ind'][:num_runs * test_every])
+        ok = inds != -1
+        rows_before = np.concatenate([[0], np.cumsum(ok)])          # valid rows among the first `count` samples
+        sel = inds[ok].astype(int)
+        var = np.array(self.collected['std'])[:len(inds)][ok].astype(float) ** 2
+        y = np.array(self.collected['y'])[:len(inds)][ok].astype(float)
+        x_rows = np.asarray(self.env.X, np.float64).reshape(self.env.num_samples, -1)[sel]
+        test_x = np.asarray(self.env.test_X, np.float64).reshape(len(self.env.test_X), -1)
+        self.gp.sync_hypers()
+        hk = self.gp.hypers()
+        c = _hip.Context(self.gp.dtype, self.gp.device)
+        try:
+            c.set_hypers(hk[0], hk[1], hk[2], hk[3])
+            c.set_pool(np.vstack([x_rows, test_x]))                 # every collected sample is a pool entry of its own
+            test_idx = np.arange(len(x_rows), len(x_rows) + len(test_x))
+            for r in range(1, num_runs + 1):
+                nr = int(rows_before[min(r * test_every, len(inds))])
+                c.set_train(np.arange(nr), y[:nr], var[:nr])
+                c.factorize(incremental=True)
+                c.set_candidates(test_idx, prior_includes_noise=False)
+                c.solve_candidates(incremental=True)
+                mu, _ = c.posterior()
+                cov, mi = c.posterior_cov(want_cov=True, want_mi=True)
+                errors.append(compute_mae(self.env.test_Y, mu))
+                mis.append(mi)
+                mean_vars.append(np.diag(cov).mean())
+        finally:
+            c.close()
         return {'mean': mu, 'error': errors, 'mi': mis, 'mean_var': mean_vars}

@@ -317,3 +317,74 @@ def test_agent_row_form_equals_fused_form():
     for (p1, c1, m1, v1), (p2, c2, m2, v2) in zip(*res):
         assert p1 == p2 and c1 == c2
         assert np.max(np.abs(m1 - m2)) < 1e-8 and np.max(np.abs(v1 - v2)) < 1e-9
+
+
+def test_prediction_vs_distance_prefixes_match_oracle():
+    """f3: the prefix sweep (agent.py:497-518) through ONE context with factor / solve updates equals a from-scratch
+    posterior per prefix (oracle), including re-measured sites (two rows of the same site) and skipped poses (-1)."""
+    from algp_amd.agent import Agent
+    rng = np.random.RandomState(5)
+    R, Cc = 16, 15
+    grid, field = O.generate_gaussian_data(R, Cc, k=5, rng=rng)
+    X = grid.astype(np.float64)
+    n = len(X)
+    perm = rng.permutation(n)
+    test = perm[:30]
+    hyp = O.Hypers(np.log([2.5, 3.0]), np.log(0.9), np.log(0.02))
+    a = Agent.__new__(Agent)
+    a.env = types.SimpleNamespace(num_samples=n, X=X, test_X=X[test], test_Y=field[test])
+    a.gp = make_gp(hyp, X[:2], np.zeros(2), None)
+    a._cov_matrix, a._cov_matrix_user, a._pool_key = None, False, None
+    walk = [int(i) for i in rng.permutation(perm[30:])[:150]]
+    walk[7] = -1                                                   # a pose off the sampling grid (agent.py:500-501)
+    walk[40] = walk[3]                                             # re-measured site: a second row, not a fused one
+    walk[90] = -1
+    stds = [0.1 if k % 5 == 0 else 1.0 for k in range(len(walk))]
+    ys = [float(field[i] + (0.05 if i >= 0 else 0.0)) if i >= 0 else -1.0 for i in walk]
+    a.collected = {'ind': walk, 'std': stds, 'y': ys}
+    test_every, runs = 37, 4
+    res = a.prediction_vs_distance(test_every, runs)
+    assert len(res['error']) == runs and len(res['mi']) == runs
+    for r in range(1, runs + 1):
+        cnt = r * test_every
+        idx = np.array(walk[:cnt])
+        ok = idx != -1
+        ref = O.posterior_chol(hyp, X[idx[ok]], np.array(ys[:cnt])[ok], X[test], np.array(stds[:cnt])[ok] ** 2, want_cov=True)
+        assert res['error'][r - 1] == pytest.approx(np.mean(np.abs(field[test] - ref['mu'])), rel=1e-9, abs=1e-11)
+        assert res['mean_var'][r - 1] == pytest.approx(np.mean(np.diag(ref['cov'])), rel=1e-8)
+        assert res['mi'][r - 1] == pytest.approx(ref['mi'], rel=1e-7, abs=1e-7)
+    assert np.max(np.abs(res['mean'] - ref['mu'])) < 1e-9
+
+
+def test_greedy_after_a_foreign_pool_load_reloads_its_pool(golden):
+    """A pool loaded into the shared context by somebody else (GPR.predict, predictive_distribution) must not be
+    indexed by the agent's next greedy: the picks equal a fresh agent's."""
+    from algp_amd.utils import predictive_distribution
+    g = golden('g3_greedy')
+    pre = 'g3_n64_'
+    sd, md = _state_lists(g[pre + 'both_static'], g[pre + 'both_mobile'])
+    hyp = _hyp(g, pre)
+    X = g[pre + 'X']
+
+    def agent():
+        b = _agent(None, sd, md, 'entropy', X=X)
+        b.gp = make_gp(hyp, X[:2], np.zeros(2), None)
+        return b
+    a = agent()
+    first = a.greedy(4)
+    rng = np.random.RandomState(0)
+    # a foreign pool with MORE rows than the agent's (silently wrong picks before the generation counter)
+    predictive_distribution(a.gp, rng.uniform(0, 8, (90, 2)), rng.uniform(size=90), rng.uniform(0, 8, (40, 2)), return_var=True)
+    assert a.greedy(4) == first == agent().greedy(4)
+
+
+def test_wrong_input_width_is_rejected():
+    from algp_amd import _hip
+    c = _hip.Context(np.float64)
+    c.set_hypers(np.log([1.0, 2.0]), 0.0, np.log(0.1))
+    with pytest.raises(ValueError):
+        c.set_pool(np.zeros((10, 3)))
+    with pytest.raises(ValueError):
+        c.kernel_matrix(np.zeros((4, 2)), np.zeros((5, 1)))
+    c.set_pool(np.zeros((10, 2)))
+    c.close()
