@@ -906,6 +906,22 @@ struct Impl {
         if (c->train_has_repeats)
             return fail(c, ALGP_ERR_STATE, "mutual_information: the train set lists a site more than once; fuse its readings first");
         const double vf = 1.0 / (1.0 / ss + 1.0 / sm), delta = vf - sm;
+        {
+            // The criterion needs diag(C_rest^-1) and diag((C + D)^-1) over the WHOLE pool: two n_pool^2 matrices
+            // (the factor and its triangular inverse).  Say so with the byte count instead of failing half-way
+            // through the allocations -- at the C4 size (110 000 sites, fp64) that is 194 GB.
+            const int64_t npad = round_up(std::max<int64_t>(n, 1), NB);
+            const size_t need = sizeof(T) * (size_t)npad * (size_t)npad * 2 + sizeof(T) * (size_t)npad * NB;
+            const size_t held = c->auxA.cap + c->auxW.cap + c->auxInv.cap;
+            size_t free_b = 0, total_b = 0;
+            ALGP_HIP(hipMemGetInfo(&free_b, &total_b));
+            if (need > held + free_b)
+                return fail(c, ALGP_ERR_OOM,
+                            "mutual_information: the criterion needs the inverse diagonals of two pool-wide matrices: " +
+                                std::to_string(need) + " bytes of scratch for n_pool = " + std::to_string(n) + ", " +
+                                std::to_string(held + free_b) + " available; score this pool with the entropy criterion "
+                                "(it needs the candidates' rows only) or a smaller pool");
+        }
         // current state: train set (with its noise) + committed picks
         std::vector<char> sampled(n, 0);
         std::vector<double> noise(n, 0.0);

@@ -1,8 +1,8 @@
 // gemm.hip -- D = alpha * A * B^T + beta * C on the gfx950 matrix cores, fp64 and fp32.
 //
-// This one kernel carries every O(n^3) term of the path: the Cholesky panel solve and trailing
-// (SYRK) update, the candidate solve V^T = B^T L^-T, and the posterior covariance V^T V.
-// All three are "NT" products with both operands contiguous along k, so one staging path serves.
+// This one kernel carries the O(n^2 m) terms of the path outside the one-launch factorisation: the candidate
+// solve V^T = B^T L^-T, the posterior covariance V^T V, the factor updates and the launch-sequence Cholesky.
+// All are "NT" products with both operands contiguous along k, so one staging path serves.
 //
 // Shape: 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each wave 64 x 64 =
 // 4 x 4 MFMA tiles of 16 x 16).
@@ -13,15 +13,15 @@
 // row piece instead (2 f64 / 4 f32 consecutive k per chunk): one ds_read_b128 then feeds 2 (f64) or 4 (f32)
 // MFMA k-steps, and A and B use the same permutation so products pair up.
 //
-// Shipped kernel (gemm_nt_kernel_dma4, variant 5): k advances 64 bytes per row per step (8 f64 / 16 f32); the
-// operand pieces go global -> LDS by DMA (global_load_lds_dwordx4, no staging registers, no ds_write pass)
-// into FOUR 16 KB stages, three k-tiles in flight while one is multiplied, with hand-placed
-// s_waitcnt vmcnt(8/4/0) + s_barrier per k-tile; two workgroups per CU (64 KB LDS, 178 VGPRs each).
+// The kernel (gemm_nt_kernel_dma4): k advances 64 bytes per row per step (8 f64 / 16 f32); the operand pieces go
+// global -> LDS by DMA (global_load_lds_dwordx4, no staging registers, no ds_write pass) into FOUR 16 KB stages,
+// three k-tiles in flight while one is multiplied, with hand-placed s_waitcnt vmcnt(8/4/0) + s_barrier per k-tile;
+// two workgroups per CU (64 KB LDS, 178 VGPRs each).
 // LDS image per operand and stage: [128 rows][4 chunks of 16 B], chunk index XOR ((row>>2)&3).
-// The register-staged kernel it replaced (gemm_nt_kernel_v0, variant 0: 128-byte rows, two 32 KB stages,
-// XOR swizzle ((row>>1)&7), one k-tile of register prefetch, 221 VGPRs) and the two-stage DMA kernel
-// (variant 1) stay selectable for A/B runs: ALGP_GEMM_VARIANT / algp_bench_gemm.
-//   fp64 4096^3: 64.6 (v0) -> 71.0 TFLOP/s (90 % of 78.6); candidate solve in situ 64.8 -> 68.4 TFLOP/s.
+// Round 1 measured its predecessors against it -- register-staged with one k-tile of prefetch (64.6 TFLOP/s at fp64
+// 4096^3), two-stage LDS-DMA, fragment double-buffering, s_setprio around the MFMAs, 5 stages, 3 workgroups per CU --
+// all slower (profiles/r01_gemm_ab_f64.txt); they are no longer in the source.
+//   fp64 4096^3: 71.0 TFLOP/s (90 % of 78.6); candidate solve in situ 68 TFLOP/s.
 //
 // Requirements (the library pads every matrix to multiples of 128 with zeros / identity):
 //   m % 128 == 0, n % 128 == 0, k % 128 == 0, leading dimensions multiples of 4 elements,
@@ -31,14 +31,6 @@
 #include "mfma.h"
 
 namespace algp {
-
-// Diagnostic builds only (tools/gemm_clock.hip): shader-clock / wall-clock ticks of wave 0 of each block.
-#ifdef ALGP_GEMM_CLOCK
-__device__ unsigned long long g_gemm_clk[2 * 8192];
-#endif
-
-int g_gemm_variant = -1;  // -1 = default (5, or ALGP_GEMM_VARIANT); 0 register-staged, 1 two-stage LDS-DMA, 2/3 v0
-                          // experiments, 5 four-stage LDS-DMA (shipped), 6 = 5 + fragment double-buffering
 
 template <typename T>
 struct GemmArgs {
@@ -53,343 +45,20 @@ struct GemmArgs {
     int lower_only;
 };
 
-template <typename T, int VAR>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel_v0(GemmArgs<T> g) {
-    using F = MF<T>;
-    using acc_t = typename F::acc_t;
-    using chunk_t = typename F::chunk_t;
-    constexpr int EPC = F::EPC;
-    constexpr int BK = 8 * EPC;
-
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * 128];
-
-    // ---- workgroup -> tile: XCD-aware (blocks b, b+8, ... share an L2), bijective remap ----
-    const int nwg = gridDim.x;
-    int sid;
-    {
-        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
-        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    }
-    int bm, bn;
-    if (g.lower_only) {
-        bm = (int)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= sid) ++bm;
-        while ((int64_t)bm * (bm + 1) / 2 > sid) --bm;
-        bn = sid - (int)((int64_t)bm * (bm + 1) / 2);
-    } else {
-        bm = sid / g.tiles_n;
-        bn = sid - bm * g.tiles_n;
-    }
-    const int64_t m0 = (int64_t)bm * 128, n0 = (int64_t)bn * 128;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    // ---- staging assignment: chunk id = tid + 256*i -> row = (tid>>3) + 32*i, chunk = tid&7 ----
-    const int lrow = tid >> 3, lch = tid & 7;
-    const int64_t bz = blockIdx.y;
-    const T* Ag = g.A + bz * g.sA + (m0 + lrow) * g.lda + lch * EPC;
-    const T* Bg = g.B + bz * g.sB + (n0 + lrow) * g.ldb + lch * EPC;
-    const int woff = lrow * 128 + ((lch ^ ((lrow >> 1) & 7)) << 4);   // (row+32i)>>1 & 7 is i-independent
-
-    chunk_t ra[4], rb[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const chunk_t*>(Ag + (int64_t)(32 * i) * g.lda + (int64_t)kt * BK);
-            rb[i] = *reinterpret_cast<const chunk_t*>(Bg + (int64_t)(32 * i) * g.ldb + (int64_t)kt * BK);
-        }
-    };
-    auto lstore = [&](int stage) {
-        char* As = smem + stage * 32768;
-        char* Bs = As + 16384;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<chunk_t*>(As + woff + i * 4096) = ra[i];
-            *reinterpret_cast<chunk_t*>(Bs + woff + i * 4096) = rb[i];
-        }
-    };
-
-    // ---- fragment read offsets: row = w*64 + t*16 + (lane&15); swizzle = (lane&15)>>1 ----
-    const int fr = lane & 15, fg = lane >> 4, fsw = fr >> 1;
-    const int aoff = (wr * 64 + fr) * 128;
-    const int boff = (wc * 64 + fr) * 128;
-
-    acc_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-#ifdef ALGP_GEMM_CLOCK
-    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-    int cur = 0;
-    if (VAR == 2) {
-        // fragment double-buffering: the ds_reads of the next 32-MFMA group fly under the current group
-        chunk_t a0[4], b0[4], a1[4], b1[4];
-        auto fread = [&](const char* As, int q, chunk_t (&a)[4], chunk_t (&b)[4]) {
-            const char* Bs = As + 16384;
-            const int coff = (((4 * q + fg) ^ fsw) << 4);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 2048 + coff);
-                b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 2048 + coff);
-            }
-        };
-        auto fmac = [&](const chunk_t (&a)[4], const chunk_t (&b)[4]) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
-        };
-        fread(smem, 0, a0, b0);
-        for (int kt = 0; kt < g.ktiles; ++kt) {
-            const bool more = (kt + 1 < g.ktiles);
-            if (more) gload(kt + 1);
-            fread(smem + cur * 32768, 1, a1, b1);
-            fmac(a0, b0);
-            fmac(a1, b1);
-            if (more) lstore(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-            if (more) fread(smem + cur * 32768, 0, a0, b0);
-        }
-    } else {
-    for (int kt = 0; kt < g.ktiles; ++kt) {
-        const bool more = (kt + 1 < g.ktiles);
-        if (more) gload(kt + 1);
-        const char* As = smem + cur * 32768;
-        const char* Bs = As + 16384;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int coff = (((4 * q + fg) ^ fsw) << 4);
-            chunk_t a[4], b[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 2048 + coff);
-                b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 2048 + coff);
-            }
-            if (VAR == 3) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
-            if (VAR == 3) __builtin_amdgcn_s_setprio(0);
-        }
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    }
-
-#ifdef ALGP_GEMM_CLOCK
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-        g_gemm_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
-        g_gemm_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-    }
-#endif
-    // ---- epilogue: D = alpha*acc + beta*C; all C loads of a 16-row slab are issued before use ----
-    const T alpha = g.alpha, beta = g.beta;
-    const T* Cb = g.C + bz * g.sC;
-    T* Db = g.D + bz * g.sD;
-    if (beta != (T)0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            T cv[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cv[r][j] = Cb[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// v1: same tile and LDS image, but
-//   * staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass.  The
-//     LDS destination of one wave-instruction is linear (base + lane*16 = 8 rows x 128 B), so the
-//     XOR swizzle is applied to the per-lane SOURCE address instead (chunk = slot ^ ((row>>1)&7));
-//   * fragments double-buffered in registers: the ds_reads of the next 32-MFMA group are issued
-//     before the current group's MFMAs, so LDS latency hides under the 64-cycle MFMAs;
-//   * epilogue loads all C values first (one batch of loads, one wait), then stores.
-// ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
-    using F = MF<T>;
-    using acc_t = typename F::acc_t;
-    using chunk_t = typename F::chunk_t;
-    constexpr int EPC = F::EPC;
-    constexpr int BK = 8 * EPC;
-
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * 128 * 128];
-
-    const int nwg = gridDim.x;
-    int sid;
-    {
-        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
-        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    }
-    int bm, bn;
-    if (g.lower_only) {
-        bm = (int)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= sid) ++bm;
-        while ((int64_t)bm * (bm + 1) / 2 > sid) --bm;
-        bn = sid - (int)((int64_t)bm * (bm + 1) / 2);
-    } else {
-        bm = sid / g.tiles_n;
-        bn = sid - bm * g.tiles_n;
-    }
-    const int64_t m0 = (int64_t)bm * 128, n0 = (int64_t)bn * 128;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-
-    // ---- LDS-DMA assignment: wave w stages 8-row groups {w, w+4, w+8, w+12} of each operand ----
-    // lane l -> row 8*grp + (l>>3), LDS slot l&7, which must hold chunk (l&7) ^ ((row>>1)&7);
-    // (row>>1)&7 = (4*grp + (l>>4)) & 7 and grp&1 == wave&1 for all four groups.
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-    const int64_t bz = blockIdx.y;
-    const T* Ag = g.A + bz * g.sA + (m0 + 8 * wave + srow) * g.lda + schunk * EPC;
-    const T* Bg = g.B + bz * g.sB + (n0 + 8 * wave + srow) * g.ldb + schunk * EPC;
-    auto stage = [&](int st, int kt) {
-        char* As = smem + st * 32768 + wave * 1024;
-        char* Bs = As + 16384;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_vp)(Ag + (int64_t)(32 * i) * g.lda + (int64_t)kt * BK),
-                                             (lds_vp)(As + i * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_vp)(Bg + (int64_t)(32 * i) * g.ldb + (int64_t)kt * BK),
-                                             (lds_vp)(Bs + i * 4096), 16, 0, 0);
-        }
-    };
-
-    const int fr = lane & 15, fg = lane >> 4, fsw = fr >> 1;
-    const int aoff = (wr * 64 + fr) * 128;
-    const int boff = (wc * 64 + fr) * 128;
-    const int coff0 = ((fg ^ fsw) << 4), coff1 = (((4 + fg) ^ fsw) << 4);
-
-    acc_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
-
-    chunk_t a0[4], b0[4], a1[4], b1[4];
-    auto fread = [&](const char* As, int coff, chunk_t (&a)[4], chunk_t (&b)[4]) {
-        const char* Bs = As + 16384;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = *reinterpret_cast<const chunk_t*>(As + aoff + t * 2048 + coff);
-            b[t] = *reinterpret_cast<const chunk_t*>(Bs + boff + t * 2048 + coff);
-        }
-    };
-    auto fmac = [&](const chunk_t (&a)[4], const chunk_t (&b)[4]) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
-    };
-
-    stage(0, 0);
-    __syncthreads();            // hipcc drains vmcnt(0) before the barrier: stage 0 has landed
-    fread(smem, coff0, a0, b0);
-
-    int cur = 0;
-    for (int kt = 0; kt < g.ktiles; ++kt) {
-        const bool more = (kt + 1 < g.ktiles);
-        if (more) stage(cur ^ 1, kt + 1);          // stage cur^1 was last read before the previous barrier
-        const char* As = smem + cur * 32768;
-        fread(As, coff1, a1, b1);                  // next group's fragments fly under this group's MFMAs
-        fmac(a0, b0);
-        fmac(a1, b1);
-        __syncthreads();                           // vmcnt(0) + barrier: next stage complete and visible
-        cur ^= 1;
-        if (more) fread(smem + cur * 32768, coff0, a0, b0);
-    }
-
-    const T alpha = g.alpha, beta = g.beta;
-    const T* Cb = g.C + bz * g.sC;
-    T* Db = g.D + bz * g.sD;
-    if (beta != (T)0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            T cv[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cv[r][j] = Cb[gi * g.ldc + n0 + wc * 64 + j * 16 + fr];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gi = m0 + wr * 64 + i * 16 + F::row_of(lane, r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
-            }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// v2 (variant 5, experiment): LDS-DMA staging with FOUR stages of 64-byte rows (4 x 16 KB, still two
-// workgroups per CU) and hand-placed waits, so that the loads of THREE k-tiles (8 f64 / 16 f32 wide each)
-// are in flight while one is multiplied -- the register-staged kernel can only keep one 128-byte k-tile
-// ahead (221 of 256 VGPRs).  Per k-tile and wave: s_waitcnt vmcnt(8) (own DMA of this tile landed, two
+// LDS-DMA staging with FOUR stages of 64-byte rows (4 x 16 KB, two workgroups per CU) and hand-placed waits, so
+// that the loads of THREE k-tiles (8 f64 / 16 f32 wide each) are in flight while one is multiplied.  Per k-tile and wave: s_waitcnt vmcnt(8) (own DMA of this tile landed, two
 // younger tiles may still fly), s_barrier (everybody's DMA landed, everybody is done reading the stage
 // that is refilled next), 4 global_load_lds for tile kt+3, then 8 ds_read_b128 + 32 MFMAs.
 // LDS image per operand and stage: [128 rows][4 chunks of 16 B], chunk index XOR ((row>>2)&3): a
 // ds_read_b128 of 16 consecutive rows at one chunk index touches 16 distinct 16-byte bank groups.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DB, int NST, int MINB>
-__global__ __launch_bounds__(256, MINB) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
+    constexpr int NST = 4;
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     using chunk_t = typename F::chunk_t;
@@ -477,54 +146,23 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel_dma4(GemmArgs<T> g) 
     };
     // wait until this wave's DMA of a tile has landed while `younger` (0..2) later tiles may still fly, then meet
     auto arrive = [&](int younger) {
-        if (younger >= 3 && NST >= 5) __builtin_amdgcn_s_waitcnt(0x0F7C);       // vmcnt(12)
-        else if (younger >= 2 && NST >= 4) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+        if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);                   // vmcnt(8)
         else if (younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F74);              // vmcnt(4)
         else __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
 
-#ifdef ALGP_GEMM_CLOCK
-    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    if (DB == 0) {
-        int st = 0;                                                // stage of tile kt; tile kt+NST-1 goes to st-1 (mod NST)
-        for (int kt = 0; kt < nkt; ++kt) {
-            arrive(nkt - 1 - kt);
-            chunk_t a[4], b[4];
-            fread(st, a, b);
-            if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);   // the stage read in iteration kt-1
-            fmac(a, b);
-            st = (st + 1 == NST) ? 0 : st + 1;
-        }
-    } else {
-        // fragments double-buffered: the ds_reads of tile kt+1 fly under the MFMAs of tile kt (tile kt+3 is
-        // issued while tile kt is multiplied and has to land two tiles later)
-        chunk_t a0[4], b0[4], a1[4], b1[4];
-        arrive(nkt - 1);
-        fread(0, a0, b0);
-        for (int kt = 0; kt < nkt; kt += 2) {                      // nkt is even
-            const bool more = kt + 2 < nkt;                        // then kt + 3 < nkt as well
-            arrive(more ? 1 : 0);
-            fread((kt + 1) & 3, a1, b1);
-            if (more) stage((kt + 3) & 3, kt + 3);
-            fmac(a0, b0);
-            if (more) {
-                arrive(1);
-                fread((kt + 2) & 3, a0, b0);
-            }
-            if (kt + 4 < nkt) stage(kt & 3, kt + 4);
-            fmac(a1, b1);
-        }
+    int st = 0;                                                    // stage of tile kt; tile kt+NST-1 goes to st-1 (mod NST)
+    for (int kt = 0; kt < nkt; ++kt) {
+        arrive(nkt - 1 - kt);
+        chunk_t a[4], b[4];
+        fread(st, a, b);
+        if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);   // the stage read in iteration kt-1
+        fmac(a, b);
+        st = (st + 1 == NST) ? 0 : st + 1;
     }
 
-#ifdef ALGP_GEMM_CLOCK
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-        g_gemm_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
-        g_gemm_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-    }
-#endif
     const T alpha = g.alpha, beta = g.beta;
     const T* Cb = g.C + bz * g.sC;
     T* Db = g.D + bz * g.sD;
@@ -583,14 +221,7 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
                                               (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     ProfScope ps(c, klass, flops, bytes);
     const dim3 grid((unsigned)tiles, (unsigned)batch);
-    static const int default_variant = getenv("ALGP_GEMM_VARIANT") ? atoi(getenv("ALGP_GEMM_VARIANT")) : 5;
-    const int variant = g_gemm_variant >= 0 ? g_gemm_variant : default_variant;
-    if (variant == 0) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 0>), grid, dim3(256), 0, c->cur, g);
-    else if (variant == 1) hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(256), 0, c->cur, g);
-    else if (variant == 2) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 2>), grid, dim3(256), 0, c->cur, g);
-    else if (variant == 3) hipLaunchKernelGGL((gemm_nt_kernel_v0<T, 3>), grid, dim3(256), 0, c->cur, g);
-    else if (variant == 6) hipLaunchKernelGGL((gemm_nt_kernel_dma4<T, 1, 4, 2>), grid, dim3(256), 0, c->cur, g);
-    else hipLaunchKernelGGL((gemm_nt_kernel_dma4<T, 0, 4, 2>), grid, dim3(256), 0, c->cur, g);
+    hipLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -670,8 +301,7 @@ int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lo
     hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, c->cur, (T*)a.p, m * k, 1u);
     hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, c->cur, (T*)b.p, n * k, 2u);
     hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->cur, (T*)cc.p, m * n, 3u);
-    const int saved = g_gemm_variant;
-    g_gemm_variant = variant;
+    (void)variant;                                                 // reserved (round 1's A/B kernels are gone)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -688,7 +318,6 @@ int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lo
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / (reps > 0 ? reps : 1);
-    g_gemm_variant = saved;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     hipFree(a.p); hipFree(b.p); hipFree(cc.p);

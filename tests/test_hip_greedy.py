@@ -157,13 +157,11 @@ def test_commit_remote_winner_equals_local(ctx64):
         c.commit_pick(int(picks[p]), 0.1, 1.0)
 
 
-@pytest.mark.parametrize('pipeline', ['0', '1'])
 @pytest.mark.parametrize('dtname', ['f64', 'f32'])
-def test_fit_and_solve_pipeline_equals_separate_calls(dtname, pipeline, monkeypatch):
-    """algp_fit_and_solve (Cholesky overlapped with the candidate solve on several streams) must give
-    what algp_factorize + algp_solve_candidates give; big enough to take the pipelined route."""
-    if pipeline == '1':
-        pytest.skip('the overlapped variant is read once per process from ALGP_PIPELINE; covered by tools/pipeline_check.py')
+def test_fit_and_solve_equals_separate_calls(dtname):
+    """algp_fit_and_solve (one planning step's fit + candidate solve) must give what algp_factorize +
+    algp_solve_candidates give, call after call, and report a non-positive pivot (N = 1500: the one-launch
+    dependency-driven factorisation)."""
     c = _hip.Context(np.float64 if dtname == 'f64' else np.float32)
     rng = np.random.RandomState(21)
     N, M = 1500, 9000
@@ -193,7 +191,7 @@ def test_fit_and_solve_pipeline_equals_separate_calls(dtname, pipeline, monkeypa
     c.factorize()
     c.solve_candidates()
     assert list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)) == list(picks)
-    # not positive definite inside the pipeline is reported, not swallowed
+    # not positive definite is reported with its pivot, not swallowed
     v2 = var.copy()
     v2[700] = -5.0
     c.set_train(np.arange(N), y, v2)
@@ -263,4 +261,62 @@ def test_lazy_greedy_equals_full_pass(dtname, mode):
     mixed += [w] + list(c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, k - 4))
     assert mixed == full_picks
     assert np.array_equal(c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0), s_full)
+    c.close()
+
+
+def test_mi_criterion_at_5000_sites_matches_oracle():
+    """MI criterion (agent.py:330-339) at a single-GPU size beyond the goldens: pool n = 5 000, |A| = 1 000 sampled
+    (static, mobile and both), every utility of the first pick against the fp64 oracle (two pool-wide inverses)."""
+    rng = np.random.RandomState(9)
+    R, Cc = 50, 100
+    grid, _ = O.generate_gaussian_data(R, Cc, k=5, rng=rng)
+    X = grid.astype(np.float64)
+    n = len(X)
+    hyp = O.Hypers(np.log([1.5, 1.5]), 0.0, np.log(1e-2))
+    perm = rng.permutation(n)
+    static = np.zeros(n, bool)
+    mobile = np.zeros(n, bool)
+    static[perm[:500]] = True
+    mobile[perm[400:1000]] = True                                  # 100 sites carry both readings
+    A = np.where(static | mobile)[0]
+    var = np.where(static[A] & mobile[A], 1.0 / (1.0 / 0.01 + 1.0), np.where(static[A], 0.01, 1.0))
+    Cm = O.kernel_matrix(hyp, X) + hyp.noise * np.eye(n)
+    picks, ut = O.greedy_fast(Cm, static, mobile, 0.1, 1.0, 1, 'mutual_information')
+    c = _hip.Context(np.float64)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise)
+    c.set_pool(X)
+    c.set_train(A, np.zeros(len(A)), var)
+    c.factorize()
+    cand = np.where(~static)[0]
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    s = c.scores(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0)
+    want = ut[0][cand]
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(s - want)) <= 1e-7 * scale, (np.max(np.abs(s - want)), scale)
+    # the argmax is optimal within the tolerance (near-ties on the lattice are decided by rounding)
+    assert want[int(np.argmax(s))] >= np.max(want) - 1e-7 * scale
+    c.close()
+
+
+def test_mi_criterion_reports_the_scratch_it_needs():
+    """At a pool the two pool-wide scratch matrices cannot fit (2 x 200 000^2 x 8 B = 640 GB) the MI criterion must
+    fail up front with ALGP_ERR_OOM and the byte count, leaving the context usable."""
+    rng = np.random.RandomState(1)
+    n = 200000
+    X = rng.uniform(0, 500, (n, 2))
+    c = _hip.Context(np.float64)
+    c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    c.set_pool(X)
+    A = np.arange(200)
+    c.set_train(A, np.zeros(200), np.full(200, 0.01))
+    c.factorize()
+    cand = np.arange(200, 1200)
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    with pytest.raises(MemoryError) as ei:                          # ALGP_ERR_OOM
+        c.scores(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0)
+    assert 'bytes of scratch' in str(ei.value) and str(n) in str(ei.value)
+    s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)                      # the entropy criterion still works
+    assert np.all(np.isfinite(s))
     c.close()
