@@ -81,6 +81,10 @@ SIGNATURES = {
     'algp_prof_reset': (C.c_int, [_c_ctx]),
     'algp_prof_get': (C.c_int, [_c_ctx, C.c_int, _dblp, _dblp, _dblp, _i64p]),
     'algp_cholesky_task_stats': (C.c_int, [_c_ctx, _dblp]),
+    'algp_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'algp_comm_init': (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_void_p]),
+    'algp_comm_destroy': (C.c_int, [_c_ctx]),
+    'algp_greedy_sharded': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_int, _i64p, _dblp]),
 }
 
 _lib = None
@@ -362,6 +366,32 @@ class Context(object):
         return (picks, ut) if want_utilities else picks
 
     # -- entropies ---------------------------------------------------------------
+    # -- multi-GPU: the collective behind the ABI (RCCL) ---------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes identifying a new communicator: one rank creates them, every rank passes them to comm_init."""
+        buf = C.create_string_buffer(128)
+        rc = load().algp_comm_unique_id(buf)
+        if rc != OK:
+            raise AlgpError(rc, 'algp_comm_unique_id failed (is librccl.so loadable?)')
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError('unique_id must be the 128 bytes of comm_unique_id()')
+        self._check(self.lib.algp_comm_init(self.h, int(nranks), int(rank), C.create_string_buffer(unique_id, 128)))
+
+    def comm_destroy(self):
+        self._check(self.lib.algp_comm_destroy(self.h))
+
+    def greedy_sharded(self, criterion, static_std, mobile_std, k, want_utilities=False):
+        """k picks over the candidate shards of all ranks (one RCCL all-gather per pick inside the library)."""
+        picks = np.empty(int(k), dtype=np.int64)
+        ut = np.empty(int(k), dtype=np.float64) if want_utilities else None
+        self._check(self.lib.algp_greedy_sharded(self.h, int(criterion), float(static_std), float(mobile_std), int(k),
+                                                 _i64(picks), None if ut is None else ut.ctypes.data_as(_dblp)))
+        return (picks, ut) if want_utilities else picks
+
     def entropy_from_cov(self, cov):
         cov = self._arr(cov)
         k = cov.shape[0]

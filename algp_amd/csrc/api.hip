@@ -157,6 +157,8 @@ constexpr int SC_AUXINFO = 3;
 constexpr int SC_AMAXV = 4;
 constexpr int SC_AMAXI = 5;
 constexpr int SC_PROBE = 6;
+constexpr int SC_COMMIT = 8;     // (d_c, scale) of the pick being committed
+constexpr int SC_AMAXF = 10;     // fresh[argmax] of the lazy greedy
 constexpr int SC_COUNT = 32;
 
 KmatSrc make_src(algp_ctx* c) {
@@ -1009,65 +1011,56 @@ struct Impl {
         return ALGP_OK;
     }
 
-    // row of V^T for a pool index that is not a local candidate (sharded scoring: the global winner
-    // lives on another rank).  Forward solve + the entries appended by earlier picks.
-    static int remote_row(algp_ctx* c, int64_t pool_idx, int in_train, double* dc_out) {
+    // Row of V^T for a pool index that is not a local candidate (sharded scoring: the global winner lives on another
+    // rank), entirely on the device: kernel-matrix row, forward substitution against the replicated factor, then the
+    // entries appended by earlier picks through the SAME kernels a local row goes through (rows_reduce +
+    // cand_finalize for the statistic, lazy_refresh for the picks), so the row and its statistic equal the owner's bit
+    // for bit.  The statistic stays on the device (c->remote); nothing is read back here.
+    struct RemoteSlots {            // one-row stand-ins for the per-candidate arrays, 64 bytes apart in c->remote
+        int64_t* cidx;
+        int* ckind;
+        T *ss, *dot, *dstat, *mu;
+        unsigned char* alive;
+        int* fresh;
+        double* score;
+    };
+    static RemoteSlots remote_slots(algp_ctx* c) {
+        char* b = (char*)c->remote.p;
+        RemoteSlots r;
+        r.cidx = (int64_t*)(b + 0);
+        r.ckind = (int*)(b + 64);
+        r.ss = (T*)(b + 128);
+        r.dot = (T*)(b + 192);
+        r.dstat = (T*)(b + 256);
+        r.mu = (T*)(b + 320);
+        r.alive = (unsigned char*)(b + 384);
+        r.fresh = (int*)(b + 448);
+        r.score = (double*)(b + 512);
+        return r;
+    }
+    static int remote_row(algp_ctx* c, int64_t pool_idx, int in_train) {
         const int64_t N = c->N, Npad = c->Npad, ldv = c->ldv;
         T* l = p(c->lrow);
+        ALGP_TRY(ensure(c, c->remote, 640));
+        RemoteSlots r = remote_slots(c);
         ALGP_HIP(hipMemsetAsync(l, 0, sizeof(T) * ldv, c->stream));
-        ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * 8));
-        int unit_host = in_train ? (int)c->pos_in_train[pool_idx] : -1;
-        int* unit_dev = (int*)((int64_t*)c->auxIdx.p + 1);
-        ALGP_HIP(hipMemcpyAsync(c->auxIdx.p, &pool_idx, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        ALGP_HIP(hipMemcpyAsync(unit_dev, &unit_host, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemsetAsync(c->remote.p, 0, 640, c->stream));
+        const int unit_host = in_train ? (int)c->pos_in_train[pool_idx] : -1;
+        ALGP_HIP(hipMemcpyAsync(r.cidx, &pool_idx, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemcpyAsync(r.ckind, &unit_host, sizeof(int), hipMemcpyHostToDevice, c->stream));
         KmatSrc s = make_src(c);
-        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->auxIdx.p, 1, 1, (const int64_t*)c->Aidx.p, N, Npad, nullptr, 0,
-                                unit_dev, 0, l, ldv));
+        ALGP_TRY(kmat_launch<T>(c, s, r.cidx, 1, 1, (const int64_t*)c->Aidx.p, N, Npad, nullptr, 0, r.ckind, 0, l, ldv));
         ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, c->Lld, p(c->invD), l));
-        // host finishes the (at most MAX_APPEND) appended entries: tiny dot products on downloaded rows
-        std::vector<T> lh(ldv);
-        ALGP_HIP(hipMemcpyAsync(lh.data(), l, sizeof(T) * ldv, hipMemcpyDeviceToHost, c->stream));
-        ALGP_TRY(sync(c));
-        std::vector<T> prev(ldv);
-        for (size_t q = 0; q < c->picks.size(); ++q) {
-            const int64_t nc = Npad + (int64_t)q;
-            ALGP_HIP(hipMemcpyAsync(prev.data(), p(c->prevrows) + (int64_t)q * ldv, sizeof(T) * nc, hipMemcpyDeviceToHost, c->stream));
-            ALGP_TRY(sync(c));
-            double t = 0;
-            for (int64_t r = 0; r < nc; ++r) t += (double)lh[r] * (double)prev[r];
-            double bp = 0;
-            if (!c->picks[q].in_train && !in_train) {
-                T v;
-                ALGP_TRY(pool_entry(c, c->picks[q].pool_idx, pool_idx, &v));
-                bp = (double)v;
-            }
-            lh[nc] = (T)((bp - t) * c->picks[q].scale);
-        }
-        ALGP_HIP(hipMemcpyAsync(l, lh.data(), sizeof(T) * ldv, hipMemcpyHostToDevice, c->stream));
-        ALGP_TRY(sync(c));
-        double ssq = 0;
-        for (int64_t r = 0; r < c->ncols; ++r) ssq += (double)lh[r] * (double)lh[r];
-        if (in_train) {
-            *dc_out = ssq;
-        } else {
-            T prior;
-            ALGP_TRY(pool_entry(c, pool_idx, pool_idx, &prior));
-            *dc_out = (double)prior - ssq;
-        }
+        ALGP_TRY(rows_reduce_launch<T>(c, l, 1, ldv, Npad, (const T*)nullptr, r.ss, (T*)nullptr));
+        const T prior = (T)(c->hyp.outputscale + (c->prior_noise ? c->hyp.noise : 0.0));
+        ALGP_TRY(cand_finalize_launch<T>(c, 1, r.ckind, r.cidx, c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, prior,
+                                         (const T*)nullptr, r.ss, r.dot, (T)0, r.dstat, r.mu, r.alive));
+        if (!c->picks.empty())
+            ALGP_TRY(lazy_refresh_launch<T>(c, 1, 2, 0, (const LazyPick*)c->lazypicks.p, (int)c->picks.size(), r.ckind, r.cidx,
+                                            (const T*)c->Xs.p, c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool,
+                                            c->hyp.DP, c->hyp.kernel, (T)c->hyp.outputscale, (T)c->hyp.noise, p(c->prevrows),
+                                            ldv, l, r.dstat, r.fresh, r.alive, r.score, c->lazy_ss, c->lazy_delta));
         return ALGP_OK;
-    }
-
-    // C(i, j) of the pool (with sigma_n^2 when i == j), one value, through the device kernel
-    static int pool_entry(algp_ctx* c, int64_t i, int64_t j, T* out) {
-        ALGP_TRY(ensure(c, c->auxVar, sizeof(T) * 8 + 2 * sizeof(int64_t) + 64));
-        int64_t* ij = (int64_t*)((char*)c->auxVar.p + 64);
-        int64_t host[2] = {i, j};
-        ALGP_HIP(hipMemcpyAsync(ij, host, sizeof(host), hipMemcpyHostToDevice, c->stream));
-        KmatSrc s = make_src(c);
-        ALGP_TRY(kmat_launch<T>(c, s, ij, 1, 1, ij + 1, 1, 16 / sizeof(T), nullptr, c->pool_is_cov ? 0 : 1, nullptr, 0,
-                                (T*)c->auxVar.p, 16 / sizeof(T)));
-        ALGP_HIP(hipMemcpyAsync(out, c->auxVar.p, sizeof(T), hipMemcpyDeviceToHost, c->stream));
-        return sync(c);
     }
 
     // Make `pool_idx` static-sampled.  Only the pick is recorded (its row of V^T, its scale); the other rows
@@ -1085,40 +1078,28 @@ struct Impl {
         const int64_t local = c->cand_pos[pool_idx];
         const int64_t ldv = c->ldv, ncols = c->ncols;
         const size_t q = c->picks.size();
-        double dc = 0;
+        const T* dsrc;
         if (local >= 0) {
             if (c->lazy_stale) ALGP_TRY(lazy_launch(c, 0, local, ss, delta));     // the winner's own row must be current
             ALGP_HIP(hipMemsetAsync(c->lrow.p, 0, sizeof(T) * ldv, c->stream));
             ALGP_HIP(hipMemcpyAsync(c->lrow.p, p(c->Vt) + local * ldv, sizeof(T) * ncols, hipMemcpyDeviceToDevice, c->stream));
-            T dch;
-            ALGP_HIP(hipMemcpyAsync(&dch, p(c->dstat) + local, sizeof(T), hipMemcpyDeviceToHost, c->stream));
-            ALGP_TRY(sync(c));
-            dc = (double)dch;
+            dsrc = p(c->dstat) + local;
         } else {
-            ALGP_TRY(remote_row(c, pool_idx, in_train, &dc));
+            ALGP_TRY(remote_row(c, pool_idx, in_train));
+            dsrc = remote_slots(c).dstat;
         }
-        double scale;
-        if (in_train) {
-            const double gamma = delta / (1.0 + delta * dc);
-            scale = sqrt(-gamma);
-        } else {
-            scale = 1.0 / sqrt(dc + ss);
-        }
+        // scale of the appended row, pick record, winner retired: on the device; ONE read-back (d_c, scale) per pick
+        double* sc = (double*)c->scal.p;
+        ALGP_HIP(hipMemcpyAsync(p(c->prevrows) + (int64_t)q * ldv, c->lrow.p, sizeof(T) * ldv, hipMemcpyDeviceToDevice, c->stream));
+        ALGP_TRY(commit_finalize_launch<T>(c, dsrc, in_train, ss, delta, (LazyPick*)c->lazypicks.p + q, pool_idx, ncols,
+                                           local >= 0 ? (unsigned char*)c->alive.p + local : nullptr,
+                                           local >= 0 ? (double*)c->scores.p + local : nullptr, sc + SC_COMMIT));
+        double host[2];
+        ALGP_HIP(hipMemcpyAsync(host, sc + SC_COMMIT, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        const double scale = host[1];
         if (!(scale == scale) || isinf(scale))
             return fail(c, ALGP_ERR_NOT_PD, "commit_pick: posterior variance of the pick is not positive");
-        LazyPick lp;
-        lp.pool_idx = pool_idx;
-        lp.ncols = ncols;
-        lp.scale = scale;
-        lp.in_train = in_train;
-        static const double neg_inf = -INFINITY;
-        ALGP_HIP(hipMemcpyAsync(p(c->prevrows) + (int64_t)q * ldv, c->lrow.p, sizeof(T) * ldv, hipMemcpyDeviceToDevice, c->stream));
-        ALGP_HIP(hipMemcpyAsync((LazyPick*)c->lazypicks.p + q, &lp, sizeof(lp), hipMemcpyHostToDevice, c->stream));
-        if (local >= 0) {
-            ALGP_HIP(hipMemsetAsync((unsigned char*)c->alive.p + local, 0, 1, c->stream));
-            ALGP_HIP(hipMemcpyAsync((double*)c->scores.p + local, &neg_inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
-        }
-        ALGP_TRY(sync(c));
         PickRec pr;
         pr.pool_idx = pool_idx;
         pr.in_train = in_train;
@@ -1170,12 +1151,18 @@ struct Impl {
         int64_t pos;
         double val;
         for (;;) {
-            ALGP_TRY(argmax(c, &pos, nullptr, &val));
-            if (pos < 0 || !c->lazy_stale) break;                 // all NaN, or nothing committed since the full scoring
-            int f;
-            ALGP_HIP(hipMemcpyAsync(&f, (const int*)c->fresh.p + pos, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            // argmax + how many picks its row has seen, ONE read-back per round
+            double* sc = (double*)c->scal.p;
+            ALGP_TRY(argmax_launch(c, (const double*)c->scores.p, c->M, sc + SC_AMAXV, (int64_t*)(sc + SC_AMAXI)));
+            ALGP_TRY(fresh_at_launch(c, (const int*)c->fresh.p, (const int64_t*)(sc + SC_AMAXI), sc + SC_AMAXF));
+            double host[3];
+            ALGP_HIP(hipMemcpyAsync(host, sc + SC_AMAXV, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            ALGP_HIP(hipMemcpyAsync(host + 2, sc + SC_AMAXF, sizeof(double), hipMemcpyDeviceToHost, c->stream));
             ALGP_TRY(sync(c));
-            if (f >= (int)c->picks.size()) break;                 // the maximum is an up-to-date row: it wins
+            memcpy(&pos, &host[1], sizeof(int64_t));
+            val = host[0];
+            if (pos < 0 || !c->lazy_stale) break;                 // all NaN, or nothing committed since the full scoring
+            if ((int)host[2] >= (int)c->picks.size()) break;      // the maximum is an up-to-date row: it wins
             ALGP_TRY(lazy_launch(c, 0, pos, ss, delta));          // the best bound becomes a true value ...
             ALGP_TRY(lazy_launch(c, 1, pos, ss, delta));          // ... and every bound reaching it is resolved
         }
@@ -1197,6 +1184,26 @@ struct Impl {
                 ALGP_TRY(best_candidate(c, criterion, static_std, mobile_std, nullptr, &pool_idx, nullptr));
             }
             if (picks_out) picks_out[pck] = pool_idx;
+            ALGP_TRY(commit_pick(c, pool_idx, static_std, mobile_std));
+        }
+        return ALGP_OK;
+    }
+
+    // k picks over candidate shards on several ranks: per pick the local best (lazily resolved), ONE all-gather of the
+    // (utility, pool index) pairs on the stream, first maximum in rank order, every rank commits the winner
+    // (agent.py:313-354 with the loop over candidates cut into shards)
+    static int greedy_sharded(algp_ctx* c, double static_std, double mobile_std, int k, int64_t* picks_out, double* ut_out) {
+        double* sc = (double*)c->scal.p;
+        for (int pck = 0; pck < k; ++pck) {
+            int64_t pos;
+            ALGP_TRY(best_candidate(c, ALGP_CRIT_ENTROPY, static_std, mobile_std, &pos, nullptr, nullptr));
+            // the argmax kernel's result is still on the device (SC_AMAXV / SC_AMAXI): pack, gather, reduce there
+            double win[3];
+            ALGP_TRY(comm_gather_winner(c, sc + SC_AMAXV, (const int64_t*)(sc + SC_AMAXI), (const int64_t*)c->Cidx.p, win));
+            if (win[1] < 0) return fail(c, ALGP_ERR_STATE, "greedy_sharded: no rank has a candidate left");
+            const int64_t pool_idx = (int64_t)win[1];
+            if (picks_out) picks_out[pck] = pool_idx;
+            if (ut_out) ut_out[pck] = win[0];
             ALGP_TRY(commit_pick(c, pool_idx, static_std, mobile_std));
         }
         return ALGP_OK;
@@ -1305,10 +1312,11 @@ void algp_destroy(algp_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
-                      &c->lrow, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->dag_state, &c->dag_stats, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->lrow, &c->remote, &c->commbuf, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->dag_state, &c->dag_stats, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
     dag_release(c);
+    comm_destroy(c);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (hipEvent_t e : c->sync_events) hipEventDestroy(e);
     hipStreamSynchronize(c->stream2);
@@ -1519,6 +1527,32 @@ int algp_greedy(algp_ctx* c, int criterion, double static_std, double mobile_std
     CHECK_CTX(c);
     if (k < 0 || k > MAX_APPEND) return fail(c, ALGP_ERR_BAD_ARG, "greedy: 0 <= k <= 128");
     FINISH(c, DISPATCH(c, greedy(c, criterion, static_std, mobile_std, k, forced, picks_out, ut_out)));
+}
+
+int algp_comm_unique_id(void* out128) {
+    if (!out128) return ALGP_ERR_BAD_ARG;
+    return comm_unique_id(out128, nullptr);
+}
+int algp_comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128) {
+    CHECK_CTX(c);
+    if (nranks < 1 || rank < 0 || rank >= nranks || !unique_id128) return fail(c, ALGP_ERR_BAD_ARG, "comm_init: bad arguments");
+    return comm_init(c, nranks, rank, unique_id128);
+}
+int algp_comm_destroy(algp_ctx* c) {
+    CHECK_CTX(c);
+    hipStreamSynchronize(c->stream);
+    comm_destroy(c);
+    return ALGP_OK;
+}
+int algp_greedy_sharded(algp_ctx* c, int criterion, double static_std, double mobile_std, int k, int64_t* picks_out,
+                        double* utilities_out) {
+    CHECK_CTX(c);
+    if (k < 0 || k > MAX_APPEND) return fail(c, ALGP_ERR_BAD_ARG, "greedy_sharded: 0 <= k <= 128");
+    if (criterion != ALGP_CRIT_ENTROPY)
+        return fail(c, ALGP_ERR_BAD_ARG, "greedy_sharded: only the entropy criterion shards (the MI criterion needs the "
+                                         "pool-wide complement on one GPU: use algp_greedy)");
+    if (!c->comm) return fail(c, ALGP_ERR_STATE, "greedy_sharded: call algp_comm_init first");
+    FINISH(c, DISPATCH(c, greedy_sharded(c, static_std, mobile_std, k, picks_out, utilities_out)));
 }
 
 int algp_entropy_from_cov(algp_ctx* c, const void* cov, int64_t k, double* H) {

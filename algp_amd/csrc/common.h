@@ -123,6 +123,7 @@ struct algp_ctx {
     algp::DevBuf Cidx, ckind, cextra, Vt, dstat, mu, alive, scores, lrow, tvec, amax;
     std::vector<algp::PickRec> picks;
     algp::DevBuf prevrows;   // MAX_APPEND x ldv: the l-rows of committed picks
+    algp::DevBuf remote;     // one-row stand-ins for the per-candidate arrays while a remote winner's row is rebuilt
     // lazy greedy: fresh[j] = number of committed picks already applied to row j of V^T / dstat[j]
     algp::DevBuf fresh, lazypicks;
     bool lazy_stale = false;             // some rows lag behind picks.size(): flush before reading the full state
@@ -138,6 +139,11 @@ struct algp_ctx {
     int vt_prior_noise = -1;
     bool vt_has_extra = false;
     int64_t kept_cols_last = 0;
+
+    // multi-GPU: RCCL communicator of the sharded greedy loop (comm.hip), null until algp_comm_init
+    void* comm = nullptr;
+    int comm_nranks = 1, comm_rank = 0;
+    algp::DevBuf commbuf;    // [own pair | gathered pairs | winner]
 
     // scratch for auxiliary factorizations (entropy_from_cov, set entropies, MI terms, posterior cov)
     algp::DevBuf auxA, auxInv, auxW, auxIdx, auxVar, auxD, hostStage;
@@ -233,6 +239,10 @@ template <typename T>
 int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet_acc, int* info,
                       int64_t block_row0);
 
+int comm_unique_id(void* out128, std::string* why);
+int comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128);
+void comm_destroy(algp_ctx* c);
+int comm_gather_winner(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev, double* winner3);
 void dag_release(algp_ctx* c);   // frees the cached task lists of the dependency-driven Cholesky
 // Cholesky of the npad x npad matrix A (ld), inverse diagonal blocks to invD (one dependency-driven launch, or the
 // blocked right-looking launch sequence for very small / very large matrices)

@@ -29,6 +29,11 @@ int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const Laz
                         const int64_t* cidx, const T* Xs, const T* Cp, int64_t n_pool, int DP, int kernel, T os, T noise,
                         const T* prevrows, int64_t ldv, T* Vt, T* dstat, int* fresh, const unsigned char* alive,
                         double* scores, double ss, double delta);
+// greedy commit bookkeeping on the device: scale of the appended row, pick record, winner retired, (d_c, scale) out
+template <typename T>
+int commit_finalize_launch(algp_ctx* c, const T* dsrc, int in_train, double ss, double delta, LazyPick* lp_out,
+                           int64_t pool_idx, int64_t ncols, unsigned char* alive_local, double* score_local, double* out2);
+int fresh_at_launch(algp_ctx* c, const int* fresh, const int64_t* idx, double* out);
 template <typename T>
 int kgemv_launch(algp_ctx* c, int64_t M, const int64_t* qidx, const T* Xs, int DP, int64_t N, const int64_t* aidx,
                  const T* alpha, int kernel, T os, T ybar, T* mu);

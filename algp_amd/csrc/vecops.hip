@@ -442,6 +442,54 @@ template int lazy_refresh_launch<float>(algp_ctx*, int64_t, int, int64_t, const 
                                         float*, float*, int*, const unsigned char*, double*, double, double);
 
 // ---------------------------------------------------------------------------------------------
+// greedy commit bookkeeping on the device (one thread): from the winner's statistic d_c (posterior variance, or
+// [S^-1]_cc for a train site) the scale of the appended row, the pick record the lazy refresh reads, the winner's
+// local row retired, and (d_c, scale) for the host's single read-back.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void commit_finalize_kernel(const T* dsrc, int in_train, double ss, double delta, LazyPick* lp_out,
+                                       int64_t pool_idx, int64_t ncols, unsigned char* alive_local, double* score_local,
+                                       double* out2) {
+    const double dc = (double)*dsrc;
+    const double scale = in_train ? sqrt(-(delta / (1.0 + delta * dc))) : 1.0 / sqrt(dc + ss);
+    LazyPick lp;
+    lp.pool_idx = pool_idx;
+    lp.ncols = ncols;
+    lp.scale = scale;
+    lp.in_train = in_train;
+    *lp_out = lp;
+    if (alive_local) {
+        *alive_local = 0;
+        *score_local = -INFINITY;
+    }
+    out2[0] = dc;
+    out2[1] = scale;
+}
+template <typename T>
+int commit_finalize_launch(algp_ctx* c, const T* dsrc, int in_train, double ss, double delta, LazyPick* lp_out,
+                           int64_t pool_idx, int64_t ncols, unsigned char* alive_local, double* score_local, double* out2) {
+    hipLaunchKernelGGL(commit_finalize_kernel<T>, dim3(1), dim3(1), 0, c->cur, dsrc, in_train, ss, delta, lp_out, pool_idx,
+                       ncols, alive_local, score_local, out2);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int commit_finalize_launch<double>(algp_ctx*, const double*, int, double, double, LazyPick*, int64_t, int64_t,
+                                            unsigned char*, double*, double*);
+template int commit_finalize_launch<float>(algp_ctx*, const float*, int, double, double, LazyPick*, int64_t, int64_t,
+                                           unsigned char*, double*, double*);
+
+// out[0] = fresh[*idx] (as a double; -1 when *idx < 0): rides with the argmax read-back of the lazy greedy
+__global__ void fresh_at_kernel(const int* fresh, const int64_t* idx, double* out) {
+    const int64_t i = *idx;
+    *out = i >= 0 ? (double)fresh[i] : -1.0;
+}
+int fresh_at_launch(algp_ctx* c, const int* fresh, const int64_t* idx, double* out) {
+    hipLaunchKernelGGL(fresh_at_kernel, dim3(1), dim3(1), 0, c->cur, fresh, idx, out);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused kernel-GEMV: mu_j = ybar + sum_a k(x_j, x_a) alpha_a, K never materialised (utils.py:301).
 // One wave per output; lanes stride over the train set (coordinates and alpha are L2 resident).
 // ---------------------------------------------------------------------------------------------

@@ -308,6 +308,9 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed/RCCL path even with one rank')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo only for rehearsing several ranks on ONE card (RCCL refuses duplicate devices)')
+    ap.add_argument('--collective', default='abi', choices=['abi', 'torch'],
+                    help='abi: the all-gather inside the library (algp_greedy_sharded, RCCL); torch: ShardedGreedy over '
+                         'torch.distributed (the cross-check; also what --backend gloo uses)')
     ap.add_argument('--cpu-train', type=int, default=6000)
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r02_traffic_pmc.json'))
     args = ap.parse_args()
@@ -356,6 +359,25 @@ def main():
     mine = all_cand[offs[rank]:offs[rank + 1]]
     ctx.set_candidates(mine, prior_includes_noise=True)
     comm = TorchComm(torch.device('cuda', local_rank)) if dist is not None else LocalComm()
+    collective = 'none'
+    if dist is not None:
+        collective = 'torch.distributed all_gather_into_tensor (%s)' % args.backend
+        if args.collective == 'abi' and args.backend == 'nccl':
+            # the library's own communicator: rank 0 creates the id, torch.distributed only carries the 128 bytes
+            try:
+                uid = [_hip.Context.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(world, rank, uid[0])
+                collective = 'algp_greedy_sharded: ncclAllGather of (utility, pool index) inside libalgp_hip.so'
+            except Exception as e:                                 # keep the run: fall back to the torch collective
+                print('bench: algp_comm_init failed (%s); using the torch.distributed collective' % e, file=sys.stderr)
+        flags = [1 if collective.startswith('algp') else 0]
+        t = torch.tensor(flags, dtype=torch.int32, device='cuda' if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)                   # every rank takes the same path
+        if int(t.item()) == 0 and collective.startswith('algp'):
+            ctx.comm_destroy()
+            collective = 'torch.distributed all_gather_into_tensor (%s)' % args.backend
+    use_abi = collective.startswith('algp')
 
     def barrier():
         ctx.sync()
@@ -370,6 +392,8 @@ def main():
         ctx.fit_and_solve()                                       # = algp_factorize + algp_solve_candidates
         if dist is None:
             picks = list(ctx.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks))
+        elif use_abi:
+            picks = list(ctx.greedy_sharded(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks))
         else:
             sg = ShardedGreedy(ctx, comm, all_cand)
             picks, _ = sg.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks)
@@ -450,7 +474,8 @@ def main():
                        'criterion': 'entropy (agent.py:125 default); the MI criterion (agent.py:330-339) needs pool-wide inverse '
                                     'diagonals -- 190 GB of scratch at this size, not shardable -- and is timed in extra.mi_criterion',
                        'n_train': N, 'candidates_per_gpu': Mloc, 'candidates_total': total_c,
-                       'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + position)' % world},
+                       'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + pool index)' % world,
+                       'collective': collective},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<%s> (candidate TRSM)' % ('double' if args.dtype == 'f64' else 'float'),
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                          'traffic': traffic,

@@ -187,6 +187,23 @@ int algp_commit_pick(algp_ctx* ctx, int64_t pool_idx, double static_std, double 
 int algp_greedy(algp_ctx* ctx, int criterion, double static_std, double mobile_std, int k,
                 const int64_t* forced_picks, int64_t* picks_out, double* utilities_out);
 
+/* ---- (e) multi-GPU: the loop over candidates (agent.py:317-347) cut into shards, one process and one ctx per GPU ----
+ * Every rank factorises the same train set (algp_factorize) and holds a contiguous slice of the candidate list
+ * (algp_set_candidates + algp_solve_candidates).  The only communication of the path is ONE ncclAllGather (RCCL over
+ * xGMI) of 16 bytes per rank and pick, issued by the library on the context's stream:
+ * algp_comm_unique_id: 128 opaque bytes (ncclUniqueId); one rank calls it, the caller hands them to the others.
+ * algp_comm_init: joins this ctx to a communicator of `nranks` ranks as `rank` (collective: every rank calls it).
+ * algp_greedy_sharded: k picks (entropy criterion; the MI criterion does not shard): per pick the local best
+ *   (algp_best_candidate), the all-gather of (utility, pool index), the first maximum in rank order (= np.argmax over
+ *   the concatenated scores, agent.py:349, shards being contiguous in rank order), algp_commit_pick of the winner on
+ *   every rank.  picks_out: k pool indices (equal on all ranks); utilities_out: their k utilities, or NULL.
+ * RCCL is opened with dlopen at algp_comm_init; without it these three return ALGP_ERR_HIP and nothing else is affected. */
+int algp_comm_unique_id(void* out128);
+int algp_comm_init(algp_ctx* ctx, int nranks, int rank, const void* unique_id128);
+int algp_comm_destroy(algp_ctx* ctx);
+int algp_greedy_sharded(algp_ctx* ctx, int criterion, double static_std, double mobile_std, int k, int64_t* picks_out,
+                        double* utilities_out);
+
 /* ---- a5 / a8: entropy_from_cov (utils.py:188-194) and set entropies for best_path --------
  * algp_entropy_from_cov: k*CONST + 1/2 log det cov for a host k x k SPD matrix.
  * algp_set_entropy: H(C[idx,idx] + diag(var)) for pool indices (agent.py:386-387).              */

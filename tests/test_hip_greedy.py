@@ -320,3 +320,57 @@ def test_mi_criterion_reports_the_scratch_it_needs():
     s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)                      # the entropy criterion still works
     assert np.all(np.isfinite(s))
     c.close()
+
+
+_SHARDED_ONE = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+from algp_amd import _hip
+rng = np.random.RandomState(4)
+X = rng.uniform(0, 30, (1500, 2))
+n = len(X)
+static = np.zeros(n, bool); mobile = np.zeros(n, bool)
+perm = rng.permutation(n)
+static[perm[:200]] = True; mobile[perm[150:400]] = True
+c = _hip.Context(np.float64)
+c.set_hypers(np.log([2.5, 2.5]), 0.0, np.log(1e-2))
+c.set_pool(X)
+A = np.where(static | mobile)[0]
+vf = 1.0 / (1.0 / 0.01 + 1.0)
+var = np.where(static[A] & mobile[A], vf, np.where(static[A], 0.01, 1.0))
+c.set_train(A, np.zeros(len(A)), var)
+c.factorize()
+cand = np.where(~static)[0]
+c.set_candidates(cand, prior_includes_noise=True)
+c.solve_candidates()
+want, ut = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
+c.comm_init(1, 0, _hip.Context.comm_unique_id())
+try:
+    c.greedy_sharded(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0, 2)
+    raise SystemExit('the MI criterion must be refused')
+except ValueError:
+    pass
+for rep in range(2):
+    c.factorize()
+    c.solve_candidates()
+    got, gut = c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
+    assert [int(p) for p in got] == [int(p) for p in want], (got, want)
+    for p in range(6):
+        assert gut[p] == np.nanmax(ut[p]), (p, gut[p], np.nanmax(ut[p]))
+c.comm_destroy()
+c.close()
+print('SHARDED-ONE-OK')
+"""
+
+
+def test_greedy_sharded_world_of_one_equals_greedy():
+    """The collective behind the ABI (algp_comm_init + algp_greedy_sharded) in an RCCL world of one rank: same picks
+    and utilities as algp_greedy, call after call.  In a process of its own: RCCL is opened with dlopen and must be
+    the only copy in its process (PyTorch, which other tests import, ships a second one).  More ranks need one GPU
+    per rank: unmeasured here, see DESIGN.md."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', _SHARDED_ONE % repo], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'SHARDED-ONE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
