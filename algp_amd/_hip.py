@@ -81,6 +81,7 @@ SIGNATURES = {
     'algp_prof_reset': (C.c_int, [_c_ctx]),
     'algp_prof_get': (C.c_int, [_c_ctx, C.c_int, _dblp, _dblp, _dblp, _i64p]),
     'algp_cholesky_task_stats': (C.c_int, [_c_ctx, _dblp]),
+    'algp_score_paths': (C.c_int, [_c_ctx, _i64p, C.c_int, C.c_int, C.c_double, _dblp]),
     'algp_comm_unique_id': (C.c_int, [C.c_void_p]),
     'algp_comm_init': (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_void_p]),
     'algp_comm_destroy': (C.c_int, [_c_ctx]),
@@ -366,6 +367,18 @@ class Context(object):
         return (picks, ut) if want_utilities else picks
 
     # -- entropies ---------------------------------------------------------------
+    def score_paths(self, sites, mobile_std):
+        """dH[p] = H(A u path_p) - H(A) for every row of `sites` (npaths x maxlen pool indices, -1 padded), all paths
+        in one launch from the resident candidate solve (see algp_score_paths)."""
+        sites = np.ascontiguousarray(sites, dtype=np.int64)
+        if sites.ndim != 2:
+            raise ValueError('sites must be (npaths, maxlen)')
+        out = np.empty(sites.shape[0], dtype=np.float64)
+        if sites.shape[0]:
+            self._check(self.lib.algp_score_paths(self.h, _i64(sites.ravel()), sites.shape[0], sites.shape[1], float(mobile_std),
+                                                  out.ctypes.data_as(_dblp)))
+        return out
+
     # -- multi-GPU: the collective behind the ABI (RCCL) ---------------------------------------
     @staticmethod
     def comm_unique_id():

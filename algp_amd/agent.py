@@ -392,13 +392,7 @@ class Agent(object):
         if self._use_rows():
             # row form: every path only APPENDS rows (a mobile row for each of its sites that has none yet) behind
             # the common base, even where it re-measures a static site; H is brought back to the fused form
-            utilities = []
-            for path in paths_mobile_indices:
-                A, is_static = self._train_rows(static, mobile0, extra_mobile=[j for j in path if j != -1])
-                c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))
-                c.factorize(incremental=True)
-                utilities.append(c.entropy() - self._rows_entropy_offset(A))
-            return int(np.argmax(utilities))
+            return int(np.argmax(self._path_utilities_rows(c, paths_mobile_indices, static, mobile0)))
         base = self._train_order(static | mobile0)          # sites sampled whichever path is taken
         in_base = np.zeros(n, bool)
         in_base[base] = True
@@ -424,6 +418,39 @@ class Agent(object):
                 ut -= c.set_entropy(np.arange(n), var_all)
             utilities.append(ut)
         return int(np.argmax(utilities))
+
+    def _path_utilities_rows(self, c, paths, static, mobile0, batched=True):
+        """Entropy utility of every path relative to the common base (row form).  Batched: ONE factor update + ONE
+        candidate-solve update for the base, then the posterior block of every path on the device at once
+        (algp_score_paths); the per-path loop (one factor update per path) remains for paths of more than 64 new
+        sites and as the cross-check of the tests."""
+        n = self.env.num_samples
+        pen = CONST + 0.5 * np.log(self.static_std ** 2 + self.mobile_std ** 2)     # per site that gets a second row
+        clean = [[int(j) for j in dict.fromkeys(int(v) for v in path) if j != -1 and not mobile0[j]] for path in paths]
+        if batched and max((len(p) for p in clean), default=0) <= 64:
+            A, is_static = self._train_rows(static, mobile0)
+            c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))
+            c.factorize(incremental=True)
+            c.set_candidates(np.arange(n), prior_includes_noise=True)
+            c.solve_candidates(incremental=True, alive=~static)
+            width = max(1, max(len(p) for p in clean))
+            sites = np.full((len(clean), width), -1, dtype=np.int64)
+            for k, pth in enumerate(clean):
+                sites[k, :len(pth)] = pth
+            dH = c.score_paths(sites, self.mobile_std)
+            second = np.array([sum(1 for j in pth if static[j]) for pth in clean], dtype=np.float64)
+            return dH - second * pen
+        utilities = []
+        for path in paths:
+            A, is_static = self._train_rows(static, mobile0, extra_mobile=[j for j in path if j != -1])
+            c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))
+            c.factorize(incremental=True)
+            utilities.append(c.entropy() - self._rows_entropy_offset(A))
+        ut = np.array(utilities)
+        A0, is_static0 = self._train_rows(static, mobile0)
+        c.set_train(A0, np.zeros(len(A0)), self._rows_noise(is_static0))
+        c.factorize(incremental=True)
+        return ut - (c.entropy() - self._rows_entropy_offset(A0))      # relative to the base, like the batched form
 
     # ---- the loops (agent.py:125-287, 475-518): host orchestration around the steps above -------------
     def get_samples_sequence_from_path(self, path, waypoints):

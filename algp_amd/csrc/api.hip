@@ -1189,6 +1189,46 @@ struct Impl {
         return ALGP_OK;
     }
 
+    // a8 / f3: the entropy gain of every enumerated path (agent.py:374-400 computes one slogdet per path) from ONE
+    // resident factor and candidate solve: sites[p][a] are pool indices (-1 = none); a site that already is a train
+    // row receives a second (mobile) row, a new site a first one; dH[p] = H(A u path_p) - H(A)
+    static int score_paths(algp_ctx* c, const int64_t* sites, int npaths, int maxlen, double mobile_std, double* dH) {
+        if (!c->solved) return fail(c, ALGP_ERR_STATE, "score_paths: call algp_solve_candidates first");
+        if (!c->prior_noise) return fail(c, ALGP_ERR_STATE, "score_paths: candidates were set with predictive semantics");
+        if (!c->picks.empty()) return fail(c, ALGP_ERR_STATE, "score_paths: picks were committed since the candidate solve; solve again");
+        const size_t tot = (size_t)npaths * maxlen;
+        std::vector<int64_t> cpos(tot, -1), lpos(tot, -1);
+        for (int pth = 0; pth < npaths; ++pth) {
+            int used = 0;
+            for (int a = 0; a < maxlen; ++a) {
+                const int64_t j = sites[(size_t)pth * maxlen + a];
+                if (j < 0) continue;
+                if (j >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "score_paths: index outside the pool");
+                const int64_t cp = c->cand_pos[j];
+                if (cp < 0) return fail(c, ALGP_ERR_BAD_ARG, "score_paths: site " + std::to_string(j) + " is not a resident candidate");
+                bool dup = false;
+                for (int b = 0; b < used; ++b) dup |= cpos[(size_t)pth * maxlen + b] == cp;
+                if (dup) continue;                                  // a site crossed twice is measured once (mobile mask)
+                cpos[(size_t)pth * maxlen + used] = cp;
+                lpos[(size_t)pth * maxlen + used] = c->pos_in_train[j];
+                ++used;
+            }
+            if (used > 64) return fail(c, ALGP_ERR_BAD_ARG, "score_paths: more than 64 distinct sites in a path");
+        }
+        ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * 2 * tot));
+        ALGP_TRY(ensure(c, c->hostStage, sizeof(double) * std::max<size_t>(npaths, 1)));
+        int64_t* d_c = (int64_t*)c->auxIdx.p;
+        int64_t* d_l = d_c + tot;
+        ALGP_HIP(hipMemcpyAsync(d_c, cpos.data(), sizeof(int64_t) * tot, hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemcpyAsync(d_l, lpos.data(), sizeof(int64_t) * tot, hipMemcpyHostToDevice, c->stream));
+        ALGP_TRY(path_score_launch<T>(c, d_c, d_l, npaths, maxlen, (const int64_t*)c->Cidx.p, p(c->Vt), c->ldv, c->ncols, p(c->L),
+                                      c->Lld, (const T*)c->varA.p, (const T*)c->Xs.p, c->pool_is_cov ? (const T*)c->Cp.p : nullptr,
+                                      c->n_pool, c->hyp.DP, c->hyp.kernel, c->hyp.outputscale, c->hyp.noise,
+                                      mobile_std * mobile_std, (double*)c->hostStage.p));
+        ALGP_HIP(hipMemcpyAsync(dH, c->hostStage.p, sizeof(double) * npaths, hipMemcpyDeviceToHost, c->stream));
+        return sync(c);
+    }
+
     // k picks over candidate shards on several ranks: per pick the local best (lazily resolved), ONE all-gather of the
     // (utility, pool index) pairs on the stream, first maximum in rank order, every rank commits the winner
     // (agent.py:313-354 with the loop over candidates cut into shards)
@@ -1529,6 +1569,12 @@ int algp_greedy(algp_ctx* c, int criterion, double static_std, double mobile_std
     FINISH(c, DISPATCH(c, greedy(c, criterion, static_std, mobile_std, k, forced, picks_out, ut_out)));
 }
 
+int algp_score_paths(algp_ctx* c, const int64_t* sites, int npaths, int maxlen, double mobile_std, double* dH_out) {
+    CHECK_CTX(c);
+    if (npaths < 0 || maxlen < 1 || (npaths > 0 && (!sites || !dH_out))) return fail(c, ALGP_ERR_BAD_ARG, "score_paths: bad arguments");
+    if (npaths == 0) return ALGP_OK;
+    FINISH(c, DISPATCH(c, score_paths(c, sites, npaths, maxlen, mobile_std, dH_out)));
+}
 int algp_comm_unique_id(void* out128) {
     if (!out128) return ALGP_ERR_BAD_ARG;
     return comm_unique_id(out128, nullptr);

@@ -29,6 +29,11 @@ int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const Laz
                         const int64_t* cidx, const T* Xs, const T* Cp, int64_t n_pool, int DP, int kernel, T os, T noise,
                         const T* prevrows, int64_t ldv, T* Vt, T* dstat, int* fresh, const unsigned char* alive,
                         double* scores, double ss, double delta);
+// best_path block scoring: dH of every path from the resident rows of V^T (one workgroup per path, <= 64 sites each)
+template <typename T>
+int path_score_launch(algp_ctx* c, const int64_t* cpos, const int64_t* lpos, int npaths, int maxlen, const int64_t* cidx,
+                      const T* Vt, int64_t ldv, int64_t ncols, const T* L, int64_t ldl, const T* varA, const T* Xs,
+                      const T* Cp, int64_t n_pool, int DP, int kernel, double os, double noise, double sm, double* out);
 // greedy commit bookkeeping on the device: scale of the appended row, pick record, winner retired, (d_c, scale) out
 template <typename T>
 int commit_finalize_launch(algp_ctx* c, const T* dsrc, int in_train, double ss, double delta, LazyPick* lp_out,

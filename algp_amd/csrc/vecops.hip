@@ -490,6 +490,148 @@ int fresh_at_launch(algp_ctx* c, const int* fresh, const int64_t* idx, double* o
 }
 
 // ---------------------------------------------------------------------------------------------
+// best_path block scoring (agent.py:358-403, entropy criterion): the gain of a whole path of mobile readings,
+//   dH = H(A u P) - H(A) = |P| CONST + 1/2 log det G,   G = C_PP + sigma_m^2 I - V_P^T V_P   (|P| <= 64),
+// from the rows of V^T the candidate solve left resident -- one workgroup per path, no factor update, no host round
+// trip per path.  A path entry is a local candidate position; entries with lpos >= 0 are sites that already are
+// train row lpos (a second, mobile reading of a statically sampled site): their column is C[A, j] = S e_lpos - d e_lpos,
+// so V_j = L[lpos, :]^T - d_lpos u with u = the candidate's unit row.  Accumulation in fp64 for either dtype.
+// ---------------------------------------------------------------------------------------------
+constexpr int PATH_SITES = 64;
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void path_score_kernel(const int64_t* cpos, const int64_t* lpos, int maxlen, const int64_t* cidx,
+                                                         const T* Vt, int64_t ldv, int64_t ncols, const T* L, int64_t ldl,
+                                                         const T* varA, const T* Xs, const T* Cp, int64_t n_pool, int kernel,
+                                                         double os, double noise, double sm, double* out) {
+    __shared__ double G[PATH_SITES][PATH_SITES + 1];
+    __shared__ double R[PATH_SITES][33];
+    __shared__ int64_t s_c[PATH_SITES], s_l[PATH_SITES];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int64_t* pc = cpos + (int64_t)blockIdx.x * maxlen;
+    const int64_t* pl = lpos + (int64_t)blockIdx.x * maxlen;
+    if (tid == 0) {
+        int n = 0;
+        for (int a = 0; a < maxlen && n < PATH_SITES; ++a)
+            if (pc[a] >= 0) { s_c[n] = pc[a]; s_l[n] = pl[a]; ++n; }
+        s_n = n;
+    }
+    __syncthreads();
+    const int P = s_n;
+    if (P == 0) {
+        if (tid == 0) out[blockIdx.x] = 0.0;
+        return;
+    }
+    // Gram matrix of the path's rows of V^T, 32 columns at a time; thread (ty, tx) owns G[ty + 16 i][tx + 16 j]
+    const int ty = tid >> 4, tx = tid & 15;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int64_t k0 = 0; k0 < ncols; k0 += 32) {
+        for (int e = tid; e < P * 32; e += 256) {
+            const int a = e >> 5, k = e & 31;
+            const int64_t kk = k0 + k;
+            double v = 0.0;
+            if (kk < ncols) {
+                v = (double)Vt[s_c[a] * ldv + kk];
+                const int64_t lp = s_l[a];
+                if (lp >= 0) v = (kk <= lp ? (double)L[lp * ldl + kk] : 0.0) - (double)varA[lp] * v;
+            }
+            R[a][k] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = ty + 16 * i;
+            if (a >= P) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = tx + 16 * j;
+                if (b > a) continue;                            // lower triangle
+                double s2 = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) s2 += R[a][k] * R[b][k];
+                acc[i][j] += s2;
+            }
+        }
+        __syncthreads();
+    }
+    // G = C_PP + sigma_m^2 I - Gram
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = ty + 16 * i;
+        if (a >= P) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = tx + 16 * j;
+            if (b > a) continue;
+            const int64_t pa = cidx[s_c[a]], pb = cidx[s_c[b]];
+            double cab;
+            if (Cp) {
+                cab = (double)Cp[pa * n_pool + pb];
+            } else {
+                double r2 = 0.0;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    const double df = (double)Xs[pa * DP + d] - (double)Xs[pb * DP + d];
+                    r2 += df * df;
+                }
+                if (kernel == ALGP_KERNEL_RBF) cab = os * exp(-0.5 * r2);
+                else {
+                    const double r = sqrt(r2) * 1.7320508075688772;
+                    cab = os * (1.0 + r) * exp(-r);
+                }
+                if (pa == pb) cab += noise;
+            }
+            G[a][b] = cab + (a == b ? sm : 0.0) - acc[i][j];
+        }
+    }
+    __syncthreads();
+    // Cholesky of the P x P block in LDS, column by column; log det = 2 sum log diag
+    double logdet = 0.0;
+    for (int j = 0; j < P; ++j) {
+        const double d = G[j][j];
+        if (!(d > 0.0)) { logdet = NAN; break; }                   // wave-uniform: every thread reads the same G[j][j]
+        const double rs = 1.0 / sqrt(d);
+        logdet += log(d);
+        __syncthreads();
+        for (int i = j + 1 + tid; i < P; i += 256) G[i][j] *= rs;
+        __syncthreads();
+        for (int e = tid; e < (P - j - 1) * (P - j - 1); e += 256) {
+            const int i = j + 1 + e / (P - j - 1), c2 = j + 1 + e % (P - j - 1);
+            if (c2 <= i) G[i][c2] -= G[i][j] * G[c2][j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = (double)P * ENT_CONST + 0.5 * logdet;
+}
+
+template <typename T>
+int path_score_launch(algp_ctx* c, const int64_t* cpos, const int64_t* lpos, int npaths, int maxlen, const int64_t* cidx,
+                      const T* Vt, int64_t ldv, int64_t ncols, const T* L, int64_t ldl, const T* varA, const T* Xs,
+                      const T* Cp, int64_t n_pool, int DP, int kernel, double os, double noise, double sm, double* out) {
+    if (npaths <= 0) return ALGP_OK;
+    dim3 grid((unsigned)npaths), blk(256);
+#define ALGP_PS(DPV)                                                                                                    \
+    hipLaunchKernelGGL((path_score_kernel<T, DPV>), grid, blk, 0, c->cur, cpos, lpos, maxlen, cidx, Vt, ldv, ncols, L, ldl, \
+                       varA, Xs, Cp, n_pool, kernel, os, noise, sm, out)
+    if (DP == 2) ALGP_PS(2);
+    else if (DP == 4) ALGP_PS(4);
+    else ALGP_PS(8);
+#undef ALGP_PS
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int path_score_launch<double>(algp_ctx*, const int64_t*, const int64_t*, int, int, const int64_t*, const double*, int64_t,
+                                       int64_t, const double*, int64_t, const double*, const double*, const double*, int64_t, int,
+                                       int, double, double, double, double*);
+template int path_score_launch<float>(algp_ctx*, const int64_t*, const int64_t*, int, int, const int64_t*, const float*, int64_t,
+                                      int64_t, const float*, int64_t, const float*, const float*, const float*, int64_t, int, int,
+                                      double, double, double, double*);
+
+// ---------------------------------------------------------------------------------------------
 // fused kernel-GEMV: mu_j = ybar + sum_a k(x_j, x_a) alpha_a, K never materialised (utils.py:301).
 // One wave per output; lanes stride over the train set (coordinates and alpha are L2 resident).
 // ---------------------------------------------------------------------------------------------

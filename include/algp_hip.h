@@ -187,6 +187,17 @@ int algp_commit_pick(algp_ctx* ctx, int64_t pool_idx, double static_std, double 
 int algp_greedy(algp_ctx* ctx, int criterion, double static_std, double mobile_std, int k,
                 const int64_t* forced_picks, int64_t* picks_out, double* utilities_out);
 
+/* ---- a8 / f3: Agent.best_path (agent.py:358-403), entropy criterion, all paths at once -----------------------------
+ * algp_score_paths: dH_out[p] = H(A u path_p) - H(A) for npaths enumerated paths, where path p adds a mobile reading
+ * (noise mobile_std^2) at each of its distinct sites sites[p*maxlen + a] (pool indices, -1 = no site): the reference
+ * takes one slogdet of the enlarged covariance per path (agent.py:386-399); here every path is the log-determinant of
+ * its <= 64 x 64 posterior block, computed from the rows of V^T that algp_solve_candidates left resident (all sites
+ * of all paths must be resident candidates, no pick committed since the solve).  A site that already is a train row
+ * (a statically sampled site crossed by the path) receives a second row, which is the same GP as the reference's fused
+ * noise (agent.py:100-109) up to the constant log(sigma_s^2 + sigma_m^2)/2 + CONST per such site (the caller's to
+ * subtract, see algp_amd/agent.py); the caller leaves out sites that already have a mobile row (no new reading).  The MI criterion's path utility stays with algp_set_entropy. */
+int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen, double mobile_std, double* dH_out);
+
 /* ---- (e) multi-GPU: the loop over candidates (agent.py:317-347) cut into shards, one process and one ctx per GPU ----
  * Every rank factorises the same train set (algp_factorize) and holds a contiguous slice of the candidate list
  * (algp_set_candidates + algp_solve_candidates).  The only communication of the path is ONE ncclAllGather (RCCL over

@@ -388,3 +388,45 @@ def test_wrong_input_width_is_rejected():
         c.kernel_matrix(np.zeros((4, 2)), np.zeros((5, 1)))
     c.set_pool(np.zeros((10, 2)))
     c.close()
+
+
+def test_best_path_batched_block_scoring_equals_per_path_factor_updates():
+    """f3: all paths scored at once from one resident factor + candidate solve (algp_score_paths: the log-determinant
+    of each path's posterior block) against one factor update + entropy per path, on paths that cross static sites
+    (second row), mobile sites (no new reading), repeat a site and contain off-grid poses (-1)."""
+    from algp_amd.agent import Agent
+    from algp_amd.arguments import get_args
+    from algp_amd.field import SyntheticField
+    np.random.seed(5)
+    env = SyntheticField(26, 24, num_test=40)
+    args = get_args(['--eval_only', '--kernel', 'rbf', '--max_iterations', '10', '--fraction_pretrain', '0.2'])
+    args.incremental = True
+    ag = Agent(env, args)
+    ag._setup_ipp('entropy')
+    rng = np.random.RandomState(8)
+    n = env.num_samples
+    for step in range(3):
+        picks = ag.greedy(3)
+        ag._add_samples(picks, [ag.static_std] * 3)
+        mob = [int(i) for i in rng.permutation(n)[:15]]
+        ag._add_samples(mob, [ag.mobile_std] * len(mob))
+        static, mobile = ag._masks()
+        new_static = [int(i) for i in rng.permutation(np.where(~static)[0])[:2]]
+        st = static.copy()
+        st[new_static] = True
+        paths = []
+        for k in range(40):
+            L = rng.randint(3, 30)
+            pth = [int(j) for j in rng.permutation(n)[:L]]
+            pth[rng.randint(L)] = int(rng.choice(np.where(st)[0]))            # crosses a static site
+            if mobile.any():
+                pth[rng.randint(L)] = int(rng.choice(np.where(mobile)[0]))    # and a mobile one
+            pth.insert(rng.randint(L), -1)
+            pth.append(pth[0] if pth[0] != -1 else pth[1])                    # a site crossed twice
+            paths.append(pth)
+        c = ag._load_pool()
+        ub = ag._path_utilities_rows(c, paths, st, mobile, batched=True)
+        ul = ag._path_utilities_rows(c, paths, st, mobile, batched=False)
+        assert np.all(np.isfinite(ub))
+        assert np.max(np.abs(ub - ul)) < 1e-8 * max(1.0, np.max(np.abs(ul))), np.max(np.abs(ub - ul))
+        assert int(np.argmax(ub)) == int(np.argmax(ul)) == ag.best_path(paths, new_static)

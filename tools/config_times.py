@@ -62,6 +62,45 @@ def run(name, R, C, dt, n_test):
     return name, out
 
 
-res = dict([run('C1 20x20 fp64', 20, 20, np.float64, 40), run('C2 50x40 fp64', 50, 40, np.float64, 400),
-            run('C3 100x100 fp32', 100, 100, np.float32, 1000), run('C3 100x100 fp64', 100, 100, np.float64, 1000)])
-print(json.dumps(res, indent=1))
+if 'best_path' not in sys.argv[1:]:
+    res = dict([run('C1 20x20 fp64', 20, 20, np.float64, 40), run('C2 50x40 fp64', 50, 40, np.float64, 400),
+                run('C3 100x100 fp32', 100, 100, np.float32, 1000), run('C3 100x100 fp64', 100, 100, np.float64, 1000)])
+    print(json.dumps(res, indent=1))
+
+
+def best_path_time():
+    """f3 'done' figure: Agent.best_path's block scoring of 1 000 paths of <= 32 sites at N = 10 000 train rows
+    (algp_score_paths on a resident candidate solve over the whole pool)."""
+    rng = np.random.RandomState(2)
+    R, C = 125, 100
+    xx, yy = np.meshgrid(np.arange(C), np.arange(R))
+    X = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)          # 12 500 pool sites
+    n = len(X)
+    perm = rng.permutation(n)
+    A = np.sort(perm[:10000])
+    var = rng.choice([0.01, 1.0], len(A))
+    c = _hip.Context(np.float64)
+    c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    c.set_pool(X)
+    c.set_train(A, np.zeros(len(A)), var)
+    c.factorize()
+    c.set_candidates(np.arange(n), prior_includes_noise=True)
+    c.solve_candidates()
+    rest = perm[10000:]
+    sites = np.full((1000, 32), -1, dtype=np.int64)
+    for p in range(1000):
+        L = rng.randint(8, 33)
+        sites[p, :L] = rng.permutation(rest)[:L]
+    c.score_paths(sites, 1.0)
+    ts = []
+    for rep in range(5):
+        c.sync()
+        t0 = time.perf_counter()
+        dH = c.score_paths(sites, 1.0)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    c.close()
+    return 'best_path 1000 paths x <=32 sites, N=10000', dict(score_paths_ms=float(np.median(ts)), finite=bool(np.all(np.isfinite(dH))))
+
+
+if 'best_path' in sys.argv[1:]:
+    print(json.dumps(dict([best_path_time()]), indent=1))
