@@ -36,6 +36,7 @@ SIGNATURES = {
     'algp_destroy': (None, [_c_ctx]),
     'algp_last_error': (C.c_char_p, [_c_ctx]),
     'algp_last_pivot': (C.c_int64, [_c_ctx]),
+    'algp_last_jitter': (C.c_double, [_c_ctx]),
     'algp_dtype': (C.c_int, [_c_ctx]),
     'algp_set_hypers': (C.c_int, [_c_ctx, C.c_int, C.c_int, _dblp, C.c_double, C.c_double]),
     'algp_kernel_matrix': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
@@ -323,6 +324,10 @@ class Context(object):
         mi = C.c_double()
         self._check(self.lib.algp_get_posterior_cov(self.h, _ptr(cov), C.byref(mi) if want_mi else None))
         return cov, (mi.value if want_mi else None)
+
+    def last_jitter(self):
+        """Diagonal jitter the last posterior_cov(want_mi=True) needed (0.0: none); see algp_last_jitter."""
+        return float(self.lib.algp_last_jitter(self.h))
 
     def posterior_mean(self, idx):
         idx = self._idx(idx)

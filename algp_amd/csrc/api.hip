@@ -233,8 +233,25 @@ struct Impl {
         ALGP_HIP(hipMemcpyAsync(c->Xraw.p, x, sizeof(T) * n * D, hipMemcpyHostToDevice, c->stream));
         c->n_pool = n;
         c->pool_is_cov = false;
+        // a fingerprint per site (FNV-1a over its coordinates' bytes): lets algp_factorize_from check that a factor
+        // adopted from another context was computed for the same COORDINATES, not only the same indices
+        c->site_hash.assign((size_t)n, 0);
+        const unsigned char* bytes = (const unsigned char*)x;
+        const size_t stride = sizeof(T) * (size_t)D;
+        for (int64_t i = 0; i < n; ++i) {
+            uint64_t h = 1469598103934665603ull;
+            for (size_t b = 0; b < stride; ++b) h = (h ^ bytes[(size_t)i * stride + b]) * 1099511628211ull;
+            c->site_hash[(size_t)i] = h;
+        }
         ALGP_TRY(rescale_pool(c));
         return sync(c);
+    }
+    // fingerprint of the coordinates of a train set, in row order (0 for an explicit-covariance pool)
+    static uint64_t train_sites_hash(const algp_ctx* c, const std::vector<int64_t>& idx) {
+        if (c->pool_is_cov || c->site_hash.empty()) return 0;
+        uint64_t h = 1469598103934665603ull;
+        for (int64_t i : idx) h = (h ^ c->site_hash[(size_t)i]) * 1099511628211ull;
+        return h;
     }
 
     static int set_pool_cov(algp_ctx* c, const void* cov, int64_t n) {
@@ -242,6 +259,7 @@ struct Impl {
         ALGP_HIP(hipMemcpyAsync(c->Cp.p, cov, sizeof(T) * n * n, hipMemcpyHostToDevice, c->stream));
         c->n_pool = n;
         c->pool_is_cov = true;
+        c->site_hash.clear();
         return sync(c);
     }
 
@@ -537,6 +555,10 @@ struct Impl {
         if (!same) return fail(c, ALGP_ERR_STATE, "factorize_from: hyper-parameters differ");
         if (src->N != N || src->fact_idx != c->train_idx || src->fact_var != c->train_var_host)
             return fail(c, ALGP_ERR_STATE, "factorize_from: the source factor belongs to a different train set");
+        if (c->pool_is_cov || src->pool_is_cov)
+            return fail(c, ALGP_ERR_STATE, "factorize_from: needs coordinate pools on both sides (an explicit covariance cannot be compared)");
+        if (train_sites_hash(src, src->fact_idx) != train_sites_hash(c, c->train_idx))
+            return fail(c, ALGP_ERR_STATE, "factorize_from: the two pools hold different coordinates at the train indices");
         int64_t keep = 0, p0 = 0;
         if (c->factored && c->fact_hyp_stamp == c->hyp_stamp && c->Lld > 0) {
             const int64_t lim = std::min<int64_t>(N, c->Nfact);
@@ -747,21 +769,41 @@ struct Impl {
         ALGP_TRY(ensure(c, c->auxInv, sizeof(T) * Mpad * NB));
         KmatSrc s = make_src(c);
         const T* extra = c->cextra.p ? (const T*)c->cextra.p : nullptr;
-        // cov_xx = K_xx + diag(test_var)   (utils.py:297; no likelihood noise)
-        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Cidx.p, M, Mpad, extra, 0,
-                                nullptr, 1, p(c->auxA), Mpad));
-        // cov = cov_xx - V^T V  (utils.py:305)
-        ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, Mpad, Mpad, c->Npad, (T)-1, p(c->Vt), c->ldv, p(c->Vt),
-                                   c->ldv, (T)1, p(c->auxA), Mpad, p(c->auxW), Mpad, 0));
-        if (cov_out)
-            ALGP_HIP(hipMemcpy2DAsync(cov_out, sizeof(T) * M, c->auxW.p, sizeof(T) * Mpad, sizeof(T) * M, M,
-                                      hipMemcpyDeviceToHost, c->stream));
-        ALGP_TRY(sync(c));
-        if (mi_out) {
+        c->last_jitter = 0.0;
+        // mi = H(cov_xx) - H(cov) (utils.py:314) takes the log-determinant of cov_xx = K_xx WITHOUT noise, which is
+        // singular to working precision on dense grids or with long lengthscales: the reference's slogdet then returns
+        // rounding noise (its sign is dropped, utils.py:193) where a Cholesky stops at a non-positive pivot.  Instead of
+        // aborting the caller's run, the two matrices are rebuilt with a growing jitter on BOTH diagonals (64 eps * prior
+        // variance, x100 per retry) and the jitter that was needed is reported (algp_last_jitter): a deliberate,
+        // visible divergence in a regime where the reference's own number carries no information.
+        const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+        for (int attempt = 0;; ++attempt) {
+            const double jitter = attempt == 0 ? 0.0 : 64.0 * eps * c->hyp.outputscale * pow(100.0, attempt - 1);
+            // cov_xx = K_xx + diag(test_var)   (utils.py:297; no likelihood noise)
+            ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Cidx.p, M, Mpad, extra, 0,
+                                    nullptr, 1, p(c->auxA), Mpad));
+            // cov = cov_xx - V^T V  (utils.py:305)
+            ALGP_TRY(gemm_nt_launch<T>(c, ALGP_PROF_GEMM_OTHER, Mpad, Mpad, c->Npad, (T)-1, p(c->Vt), c->ldv, p(c->Vt),
+                                       c->ldv, (T)1, p(c->auxA), Mpad, p(c->auxW), Mpad, 0));
+            if (attempt == 0 && cov_out)
+                ALGP_HIP(hipMemcpy2DAsync(cov_out, sizeof(T) * M, c->auxW.p, sizeof(T) * Mpad, sizeof(T) * M, M,
+                                          hipMemcpyDeviceToHost, c->stream));
+            ALGP_TRY(sync(c));
+            if (!mi_out) break;
+            if (jitter > 0.0) {
+                ALGP_TRY(add_diag_launch<T>(c, p(c->auxA), M, Mpad, (T)jitter));
+                ALGP_TRY(add_diag_launch<T>(c, p(c->auxW), M, Mpad, (T)jitter));
+            }
             double ld_xx = 0, ld_cov = 0;
-            ALGP_TRY(factor_resident(c, p(c->auxA), M, Mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld_xx));
-            ALGP_TRY(factor_resident(c, p(c->auxW), M, Mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld_cov));
-            *mi_out = 0.5 * (ld_xx - ld_cov);     // the k*CONST terms cancel (utils.py:314)
+            int rc = factor_resident(c, p(c->auxA), M, Mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld_xx);
+            if (rc == ALGP_OK) rc = factor_resident(c, p(c->auxW), M, Mpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld_cov);
+            if (rc == ALGP_OK) {
+                *mi_out = 0.5 * (ld_xx - ld_cov);     // the k*CONST terms cancel (utils.py:314)
+                c->last_jitter = jitter;
+                break;
+            }
+            if (rc != ALGP_ERR_NOT_PD || attempt >= 5) return rc;
+            c->err.clear();
         }
         return ALGP_OK;
     }
@@ -1369,6 +1411,7 @@ void algp_destroy(algp_ctx* c) {
 
 const char* algp_last_error(const algp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int64_t algp_last_pivot(const algp_ctx* c) { return c ? c->pivot : 0; }
+double algp_last_jitter(const algp_ctx* c) { return c ? c->last_jitter : 0.0; }
 int algp_dtype(const algp_ctx* c) { return c ? c->dtype : -1; }
 
 int algp_set_hypers(algp_ctx* c, int kernel, int D, const double* log_ls, double log_os, double log_noise) {

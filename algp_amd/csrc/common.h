@@ -71,6 +71,7 @@ struct algp_ctx {
     std::vector<hipEvent_t> sync_events;
     std::string err;
     int64_t pivot = 0;
+    double last_jitter = 0;          // diagonal jitter the last algp_get_posterior_cov needed for its MI term (0: none)
     algp::Hypers hyp;
 
     // pool
@@ -80,6 +81,7 @@ struct algp_ctx {
     algp::DevBuf Xraw;      // n x D raw coordinates (kept to rescale on a hyper change)
     algp::DevBuf Cp;        // n x n explicit covariance (pool_is_cov)
     std::vector<int64_t> pos_in_train;   // host: pool index -> position in train set or -1
+    std::vector<uint64_t> site_hash;     // host: fingerprint of every pool site's coordinates (algp_factorize_from)
 
     // train set / factor
     int64_t N = 0, Npad = 0;

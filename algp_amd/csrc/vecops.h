@@ -47,6 +47,8 @@ int pad_identity_launch(algp_ctx* c, T* A, int64_t n, int64_t npad, int64_t ld);
 template <typename T>
 int set_identity_launch(algp_ctx* c, T* A, int64_t npad, int64_t ld);
 template <typename T>
+int add_diag_launch(algp_ctx* c, T* A, int64_t n, int64_t ld, T v);
+template <typename T>
 int logdiag_launch(algp_ctx* c, const T* L, int64_t ld, int64_t n, double* out);
 template <typename T>
 int to_double_launch(algp_ctx* c, double* dst, const T* src, int64_t n);

@@ -709,6 +709,22 @@ int pad_identity_launch(algp_ctx* c, T* A, int64_t n, int64_t npad, int64_t ld) 
 template int pad_identity_launch<double>(algp_ctx*, double*, int64_t, int64_t, int64_t);
 template int pad_identity_launch<float>(algp_ctx*, float*, int64_t, int64_t, int64_t);
 
+// A[i][i] += v for i < n
+template <typename T>
+__global__ void add_diag_kernel(T* A, int64_t n, int64_t ld, T v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[i * ld + i] += v;
+}
+template <typename T>
+int add_diag_launch(algp_ctx* c, T* A, int64_t n, int64_t ld, T v) {
+    if (n <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(add_diag_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->cur, A, n, ld, v);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int add_diag_launch<double>(algp_ctx*, double*, int64_t, int64_t, double);
+template int add_diag_launch<float>(algp_ctx*, float*, int64_t, int64_t, float);
+
 template <typename T>
 __global__ void set_identity_kernel(T* A, int64_t npad, int64_t ld) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -71,6 +71,11 @@ int algp_create(int device_id, int dtype, algp_ctx** out);
 void algp_destroy(algp_ctx* ctx);
 const char* algp_last_error(const algp_ctx* ctx);
 int64_t algp_last_pivot(const algp_ctx* ctx);
+/* Diagonal jitter the last algp_get_posterior_cov had to add to cov_xx and cov before the two log-determinants of its
+ * MI term existed (0: none).  utils.py:314 takes slogdet of the noise-free K_xx, which is singular to working precision
+ * on dense grids; the reference returns rounding noise there (sign dropped, utils.py:193), this library a regularised
+ * value plus the jitter it used.  Factorisations of the TRAIN matrix never use a jitter: they fail with ALGP_ERR_NOT_PD. */
+double algp_last_jitter(const algp_ctx* ctx);
 int algp_dtype(const algp_ctx* ctx);
 
 /* ---- hyper-parameters: ExactGPModel's D+2 scalars (models.py:206-254; names run.py:35-37) ---

@@ -211,3 +211,35 @@ def test_repeated_measurements_equal_the_fused_row(ctx, mode):
     assert np.array_equal(fin, np.isfinite(u2)) and np.max(np.abs(u1[fin] - u2[fin])) < 1e-9
     assert p1 == p2
     ctx.set_constant_mean(None)
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_mi_of_a_numerically_singular_kxx_is_regularised_and_reported(dt):
+    """utils.py:314 takes slogdet of the noise-free K_xx; on a dense grid with a long lengthscale that matrix is
+    singular to working precision: the reference returns rounding noise (sign dropped), a Cholesky stops.  The
+    library retries with a reported diagonal jitter instead of aborting the caller's run; the covariance itself
+    and the train factorisation are untouched (the latter still raises)."""
+    xx, yy = np.meshgrid(np.arange(12), np.arange(12))
+    X = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)
+    n = len(X)
+    rng = np.random.RandomState(0)
+    perm = rng.permutation(n)
+    A, test = perm[:40], perm[40:]
+    c = _hip.Context(dt)
+    c.set_hypers(np.log([9.0, 9.0]), 0.0, np.log(1e-2))            # lengthscale of 9 cells: K_xx has rank ~ 20 numerically
+    c.set_pool(X)
+    c.set_train(A, np.sin(X[A, 0]), np.full(len(A), 0.01))
+    c.factorize()
+    c.set_candidates(test, prior_includes_noise=False)
+    c.solve_candidates()
+    cov, mi = c.posterior_cov(want_cov=True, want_mi=True)
+    assert np.isfinite(mi) and c.last_jitter() > 0.0
+    hyp = O.Hypers(np.log([9.0, 9.0]), 0.0, np.log(1e-2))
+    ref = O.posterior_chol(hyp, X[A], np.sin(X[A, 0]), X[test], np.full(len(A), 0.01), want_cov=True)
+    assert np.max(np.abs(cov - ref['cov'])) < (1e-9 if dt == np.float64 else 2e-3)
+    # a well-conditioned test set needs none
+    c.set_candidates(test[:3], prior_includes_noise=False)
+    c.solve_candidates()
+    _, mi2 = c.posterior_cov(want_cov=False, want_mi=True)
+    assert np.isfinite(mi2) and c.last_jitter() == 0.0
+    c.close()

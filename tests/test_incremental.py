@@ -354,5 +354,16 @@ def test_factorize_from_another_context():
         b.factorize_from(a)
     with pytest.raises(ValueError):
         a.factorize_from(a)
+    # same indices, other coordinates: refused (the pool may be larger -- only the train sites' coordinates count)
+    b.set_hypers(*hyp)
+    X2 = X.copy()
+    X2[5] += 0.25
+    b.set_pool(X2)
+    b.set_train(idx2, y2, var2)
+    with pytest.raises(ValueError):
+        b.factorize_from(a)
+    b.set_pool(np.vstack([X, rng.uniform(0, 40, (10, 2))]))
+    b.set_train(idx2, y2, var2)
+    assert b.factorize_from(a) >= 0
     for c in (a, b, ref):
         c.close()
