@@ -16,6 +16,13 @@ the factor of the sampled set, so candidates shard embarrassingly:
 
 ``backend`` is any object with the `_hip.Context` scoring surface (scores / commit_pick / M);
 tests drive the same logic over gloo with a CPU stand-in backend.
+
+Two routes exist for the exchange.  On a GPU node the one to use is behind the C ABI:
+`_hip.Context.comm_init` + `greedy_sharded` (include/algp_hip.h: algp_comm_init / algp_greedy_sharded) -- the library
+packs each rank's (utility, global position), calls RCCL's all-gather on its own stream, takes the first maximum and
+commits the winner on the device, one 16-byte read-back per pick, no host arithmetic between kernels (what
+`bench.py --collective abi`, the default, times).  This module is the torch.distributed route (`bench.py --collective
+torch`, and the gloo route the CPU tests cover): same partition, same tie-break, the collective issued by the caller.
 """
 import numpy as np
 

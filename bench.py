@@ -225,17 +225,20 @@ def extra_c5(_hip, device, picks):
     static = np.zeros(len(pool), bool)
     static[:N0] = var == 0.01
     cidx = np.arange(N0, N0 + M)
-    times, chol_ms = [], None
+    times, rows, chol_ms = [], [], None
     for s in range(11):
-        inc = s > 0
         if s == 0:
             c.prof_enable(True)
             c.prof_reset()
         t0 = time.perf_counter()
+        rows.append(int(len(idx)))
+        # incremental=True from the first step, as algp_amd/agent.py calls it: with nothing resident it is a from-scratch
+        # fit, but L and V^T get their 12.5 % row-stride headroom at once (otherwise the first 128-row growth re-lays
+        # out 60 GB: 1.8 s)
         c.set_train(idx, y, var)
-        c.factorize(incremental=inc)
+        c.factorize(incremental=True)
         c.set_candidates(cidx, prior_includes_noise=True)
-        c.solve_candidates(incremental=inc, alive=~static[cidx])
+        c.solve_candidates(incremental=True, alive=~static[cidx])
         pk = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, picks)
         c.sync()
         times.append((time.perf_counter() - t0) * 1e3)
@@ -257,6 +260,7 @@ def extra_c5(_hip, device, picks):
     return {'workload': 'C5 on one GPU: 50 000-point field, fp64, 100 000 candidates, %d picks/step' % picks, 'dtype': 'f64',
             'from_scratch_step_ms': times[0], 'incremental_step_ms_median': float(np.median(times[1:])),
             'incremental_step_ms_max': float(np.max(times[1:])), 'incremental_steps': len(times) - 1,
+            'step_ms': [round(t, 2) for t in times], 'train_rows_per_step': rows,
             'fit_ms': chol_ms, 'cholesky_tflops': ctf, 'device_gb': dev_gb,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<double> (candidate TRSM, N^2 M / wall time of the solve)',
                          'achieved': ttf, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ttf / FP64_MATRIX_PEAK_TFLOPS},
