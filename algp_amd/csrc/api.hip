@@ -1306,7 +1306,8 @@ struct Impl {
         double* sc = (double*)c->scal.p + 16;             // slots 16..27: os, trace, ls[0..8)
         ALGP_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 12, c->stream));
         ALGP_TRY(mll_grad_launch<T>(c, p(c->auxA), Npad, N, (const T*)c->Xs.p, DP, (const int64_t*)c->Aidx.p,
-                                    (const T*)c->alpha.p, c->hyp.kernel, (T)c->hyp.outputscale, sc));
+                                    (const T*)c->alpha.p, c->hyp.kernel, (T)c->hyp.outputscale, sc,
+                                    (double*)c->auxW.p /* X = L^-T is spent: room for the per-workgroup partials */));
         double h[12];
         ALGP_HIP(hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         ALGP_TRY(sync(c));

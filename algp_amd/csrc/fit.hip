@@ -16,7 +16,7 @@ namespace algp {
 template <typename T, int DP>
 __global__ __launch_bounds__(256) void mll_grad_kernel(const T* Sinv, int64_t ld, int64_t N, const T* Xs,
                                                        const int64_t* aidx, const T* alpha, int kernel, T os,
-                                                       double* out /* [0]=os, [1]=noise trace, [2..2+DP) = ls */) {
+                                                       double* partial /* per workgroup: [0]=os, [1]=noise trace, [2..2+DP) = ls */) {
     // one workgroup = a 64-row x 64-col tile of the lower triangle; the grid enumerates only those
     // (blockIdx.x -> (bi, bj <= bi)).  The 64 rows' coordinates and alpha are staged in LDS once.
     int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void mll_grad_kernel(const T* Sinv, int64_t ld
             for (int d = 0; d < DP; ++d) g_ls[d] += m * (double)(w * dk * u2[d]);
         }
     }
-    // block reduction: wave shuffles, LDS across the 4 waves, then one atomic per block and quantity
+    // block reduction: wave shuffles, LDS across the 4 waves, then one partial per block and quantity (summed in fixed
+    // order by mll_grad_reduce_kernel: the gradient, and with it a whole fit trajectory, is the same in every run)
     auto wsum = [](double v) {
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         return v;
@@ -103,25 +104,42 @@ __global__ __launch_bounds__(256) void mll_grad_kernel(const T* Sinv, int64_t ld
     }
     __syncthreads();
     if (threadIdx.x < 2 + DP)
-        atomicAdd(out + threadIdx.x, s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+        partial[(int64_t)blockIdx.x * (2 + DP) + threadIdx.x] =
+            (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// out[q] += sum over blocks of partial[b][q], q < nq: one workgroup, thread-strided then shuffle tree
+__global__ __launch_bounds__(256) void mll_grad_reduce_kernel(const double* partial, int64_t nblocks, int nq, double* out) {
+    __shared__ double part[4];
+    for (int q = 0; q < nq; ++q) {
+        double v = 0;
+        for (int64_t b = threadIdx.x; b < nblocks; b += 256) v += partial[b * nq + q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) out[q] += (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
+    }
 }
 
 template <typename T>
 int mll_grad_launch(algp_ctx* c, const T* Sinv, int64_t ld, int64_t N, const T* Xs, int DP, const int64_t* aidx,
-                    const T* alpha, int kernel, T os, double* out_dev) {
+                    const T* alpha, int kernel, T os, double* out_dev, double* partial) {
     if (N <= 0) return ALGP_OK;
     const unsigned nb = (unsigned)((N + 63) / 64);
     ProfScope ps(c, ALGP_PROF_KMAT, 0.5 * (double)N * N * (3.0 * DP + 8.0), sizeof(T) * 0.5 * (double)N * N);
     dim3 grid(nb * (nb + 1) / 2), blk(256);
-    if (DP == 2) hipLaunchKernelGGL((mll_grad_kernel<T, 2>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
-    else if (DP == 4) hipLaunchKernelGGL((mll_grad_kernel<T, 4>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
-    else hipLaunchKernelGGL((mll_grad_kernel<T, 8>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, out_dev);
+    if (DP == 2) hipLaunchKernelGGL((mll_grad_kernel<T, 2>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, partial);
+    else if (DP == 4) hipLaunchKernelGGL((mll_grad_kernel<T, 4>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, partial);
+    else hipLaunchKernelGGL((mll_grad_kernel<T, 8>), grid, blk, 0, c->cur, Sinv, ld, N, Xs, aidx, alpha, kernel, os, partial);
+    ALGP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mll_grad_reduce_kernel, dim3(1), dim3(256), 0, c->cur, partial, (int64_t)grid.x, 2 + DP, out_dev);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
 template int mll_grad_launch<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, int, const int64_t*,
-                                     const double*, int, double, double*);
+                                     const double*, int, double, double*, double*);
 template int mll_grad_launch<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, int, const int64_t*,
-                                    const float*, int, float, double*);
+                                    const float*, int, float, double*, double*);
 
 }  // namespace algp

@@ -57,5 +57,5 @@ template <typename T>
 int trinv_diag_launch(algp_ctx* c, const T* A, int64_t lda, T* inv_out);
 template <typename T>
 int mll_grad_launch(algp_ctx* c, const T* Sinv, int64_t ld, int64_t N, const T* Xs, int DP, const int64_t* aidx,
-                    const T* alpha, int kernel, T os, double* out_dev);
+                    const T* alpha, int kernel, T os, double* out_dev, double* partial);
 }  // namespace algp

@@ -745,17 +745,19 @@ template int set_identity_launch<float>(algp_ctx*, float*, int64_t, int64_t);
 // sum_i log L[i][i] for i < n, accumulated into *out (double)
 template <typename T>
 __global__ __launch_bounds__(256) void logdiag_kernel(const T* L, int64_t ld, int64_t n, double* out) {
+    // one workgroup, fixed summation order: the log-determinant of an updated factor is the same number in every run
+    __shared__ double part[4];
     double v = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        v += log((double)L[i * ld + i]);
+    for (int64_t i = threadIdx.x; i < n; i += 256) v += log((double)L[i * ld + i]);
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *out += ((part[0] + part[1]) + (part[2] + part[3]));
 }
 template <typename T>
 int logdiag_launch(algp_ctx* c, const T* L, int64_t ld, int64_t n, double* out) {
     if (n <= 0) return ALGP_OK;
-    const int64_t g = std::min<int64_t>((n + 255) / 256, 64);
-    hipLaunchKernelGGL(logdiag_kernel<T>, dim3((unsigned)g), dim3(256), 0, c->cur, L, ld, n, out);
+    hipLaunchKernelGGL(logdiag_kernel<T>, dim3(1), dim3(256), 0, c->cur, L, ld, n, out);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

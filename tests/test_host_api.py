@@ -137,6 +137,8 @@ def test_mll_and_gradient_vs_oracle_and_finite_differences(kernel):
     gp = make_gp(hyp, x, y, var, kernel=kernel)
     gp._load_train_on_device()
     loss, g = gp.neg_mll_and_grad()
+    loss2, g2 = gp.neg_mll_and_grad()                   # fixed-order reductions: the same bits every time
+    assert loss2 == loss and np.array_equal(np.asarray(g2), np.asarray(g))
     if kernel == 'rbf':
         f0, go = O.mll_and_grad(hyp, x, y, var)
         assert -loss == pytest.approx(f0, rel=1e-10)
