@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <queue>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace algp {
 
@@ -518,6 +519,7 @@ struct DagSchedule {
     int64_t nt = 0;
     int window = 0;
     std::vector<DagTask> tasks;
+    float makespan = 0;                                        // of the simulation, microseconds
 };
 
 static int batched_until(int j, int W) {                       // columns [0, kf) of tile column j arrive in batches of 4
@@ -622,6 +624,32 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         for (int s : nodes[v].succ) b = std::max(b, nodes[s].prio);
         nodes[v].prio = b + nodes[v].dur;
     }
+#ifdef ALGP_DAG_DEBUG
+    {
+        // critical path: follow the successor with the largest bottom level from the node with the largest one
+        int v = 0;
+        for (int u = 0; u < n; ++u) if (nodes[u].prio > nodes[v].prio) v = u;
+        fprintf(stderr, "critical path %.0f us:", nodes[v].prio);
+        float by_type[3] = {0, 0, 0};
+        int cnt = 0;
+        for (;;) {
+            by_type[nodes[v].t.type] += nodes[v].dur;
+            if (cnt++ < 12 || nodes[v].succ.empty())
+                fprintf(stderr, " %s(%d,%d,%d..%d)", nodes[v].t.type == 0 ? "CHAIN" : nodes[v].t.type == 1 ? "TRSM" : "UPD", nodes[v].t.i, nodes[v].t.j,
+                        nodes[v].t.kk >> 16, nodes[v].t.kk & 0xffff);
+            else if (cnt == 14) fprintf(stderr, " ...");
+            if (nodes[v].succ.empty()) break;
+            int b = nodes[v].succ[0];
+            for (int s2 : nodes[v].succ) if (nodes[s2].prio > nodes[b].prio) b = s2;
+            v = b;
+        }
+        fprintf(stderr, "\n  time on the path by type: chain %.0f trsm %.0f upd %.0f\n", by_type[0], by_type[1], by_type[2]);
+    }
+    std::vector<float> t_start(n, 0.f);
+#define DAG_SIM_START(v) t_start[v] = now
+#else
+#define DAG_SIM_START(v) do { } while (0)
+#endif
     // list scheduling of the ticketed tasks on the workers left beside the team; chain links start the moment they
     // are ready
     typedef std::pair<float, int> PI;
@@ -633,6 +661,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     int freew = workers - 2 * DAG_TEAM, started = 0;                         // the team and its retired CU neighbours
     auto release = [&](int v) {                                              // all inputs of v are there
         if (nodes[v].on_chain) {
+            DAG_SIM_START(v);
             running.push(PI(now + nodes[v].dur, v));
             ++started;
         } else {
@@ -647,6 +676,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             ready.pop();
             out.tasks.push_back(nodes[v].t);
             ++started;
+            DAG_SIM_START(v);
             running.push(PI(now + nodes[v].dur, v));
             --freew;
         }
@@ -662,6 +692,33 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     }
     out.nt = nt;
     out.window = W;
+    out.makespan = now;
+#ifdef ALGP_DAG_DEBUG
+    {
+        // the simulated machine per 500 us: ticketed workers busy, and the diagonal block the chain has reached
+        const int nb = (int)(now / 500.f) + 1;
+        std::vector<double> busy(nb, 0.0);
+        std::vector<int> chain_at(nb, 0);
+        double work = 0;
+        for (int v = 0; v < n; ++v) {
+            if (nodes[v].on_chain) {
+                if (nodes[v].t.i == nodes[v].t.j && nodes[v].dur > 40.f) chain_at[std::min(nb - 1, (int)(t_start[v] / 500.f))] = nodes[v].t.i;
+                continue;
+            }
+            work += nodes[v].dur;
+            for (float t = t_start[v]; t < t_start[v] + nodes[v].dur;) {
+                const int b = std::min(nb - 1, (int)(t / 500.f));
+                const float e = std::min(t_start[v] + nodes[v].dur, (b + 1) * 500.f);
+                busy[b] += e - t;
+                t = e;
+            }
+        }
+        fprintf(stderr, "  simulated makespan %.0f us; ticketed work %.0f workgroup-us = %.0f us on %d workers\n  per 500 us, busy workers / chain step:",
+                now, work, work / (workers - 2 * DAG_TEAM), workers - 2 * DAG_TEAM);
+        for (int b = 0; b < nb; ++b) fprintf(stderr, " %.0f/%d", busy[b] / 500.0, chain_at[b]);
+        fprintf(stderr, "\n");
+    }
+#endif
 }
 
 template <typename T>
