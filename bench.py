@@ -29,6 +29,8 @@ import numpy as np
 # a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues; once RCCL's streams exist the chunk streams
 # share a queue and serialise (TRSM 161 -> 183 ms).  Must be set before the HIP runtime initialises.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# the host driver of this pool only supports dmabuf IPC: without it RCCL's intra-node transport fails in hipIpcGetMemHandle
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
