@@ -553,7 +553,12 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     };
     // durations in microseconds as measured at N = 10 000 (bulk workgroups share a CU's matrix cores in pairs, the
     // chain team's members have their CUs to themselves); only their proportions matter
+#ifdef ALGP_DAG_DEBUG
+    auto knob = [](const char* name, float dflt) { return getenv(name) ? (float)atof(getenv(name)) : dflt; };
+    const float D_DIAG = knob("DAG_D_DIAG", 45.f), D_STRIP = knob("DAG_D_STRIP", 10.f), D_OP = knob("DAG_D_OP", 34.f), D_OVH = knob("DAG_D_OVH", 5.f);
+#else
     const float D_DIAG = 45.f, D_STRIP = 10.f, D_OP = 34.f, D_OVH = 5.f;
+#endif
     int prev_h5 = -1;
     for (int k = 0; k < nt; ++k) {
         // the chain team's work of column step k: never ticketed, but part of the simulation, where each link starts
