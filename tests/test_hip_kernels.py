@@ -67,7 +67,7 @@ def spd(n, rng, cond_shift=1.0):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('n', [1, 5, 64, 128, 129, 300, 1000])
+@pytest.mark.parametrize('n', [1, 5, 64, 128, 129, 300, 1000, 1500, 2600])   # from 8 tiles of 128 on: the one-launch task list
 def test_cholesky(ctxs, dt, n):
     rng = np.random.RandomState(n)
     A = spd(n, rng).astype(dt)
@@ -96,13 +96,21 @@ def test_cholesky_lehmer_and_pascal_exact(ctxs):
 
 
 @pytest.mark.parametrize('dt', DT)
-def test_cholesky_not_pd_reports_pivot(ctxs, dt):
+@pytest.mark.parametrize('n,bad', [(200, 150), (1500, 1301), (1500, 5)])    # launch sequence; task list: late and first tile
+def test_cholesky_not_pd_reports_pivot(ctxs, dt, n, bad):
     rng = np.random.RandomState(0)
-    A = spd(200, rng)
-    A[150, 150] = -5.0
+    A = spd(n, rng)
+    A[bad, bad] = -5.0
     with pytest.raises(np.linalg.LinAlgError) as ei:
         ctxs[np.dtype(dt)].cholesky(A.astype(dt))
-    assert ei.value.pivot == 151
+    assert ei.value.pivot == bad + 1
+    # the context is usable afterwards, and a matrix with a NaN is refused as well (no hang in the task list's waits)
+    L, _ = ctxs[np.dtype(dt)].cholesky(spd(n, rng).astype(dt))
+    assert np.all(np.isfinite(L))
+    A = spd(n, rng)
+    A[bad, bad // 2] = A[bad // 2, bad] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        ctxs[np.dtype(dt)].cholesky(A.astype(dt))
 
 
 @pytest.mark.parametrize('dt', DT)
