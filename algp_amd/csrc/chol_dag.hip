@@ -557,7 +557,12 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     auto knob = [](const char* name, float dflt) { return getenv(name) ? (float)atof(getenv(name)) : dflt; };
     const float D_DIAG = knob("DAG_D_DIAG", 45.f), D_STRIP = knob("DAG_D_STRIP", 10.f), D_OP = knob("DAG_D_OP", 34.f), D_OVH = knob("DAG_D_OVH", 5.f);
 #else
+#ifdef ALGP_DAG_DEBUG
+    auto knob = [](const char* name, float dflt) { return getenv(name) ? (float)atof(getenv(name)) : dflt; };   // what-if runs of the probe
+    const float D_DIAG = knob("DAG_D_DIAG", 45.f), D_STRIP = knob("DAG_D_STRIP", 10.f), D_OP = knob("DAG_D_OP", 34.f), D_OVH = knob("DAG_D_OVH", 5.f);
+#else
     const float D_DIAG = 45.f, D_STRIP = 10.f, D_OP = 34.f, D_OVH = 5.f;
+#endif
 #endif
     int prev_h5 = -1;
     for (int k = 0; k < nt; ++k) {
