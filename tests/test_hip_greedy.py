@@ -374,3 +374,51 @@ def test_greedy_sharded_world_of_one_equals_greedy():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', _SHARDED_ONE % repo], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'SHARDED-ONE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize('dtname,D,kern', [('f64', 2, 'rbf'), ('f64', 3, 'rbf'), ('f64', 6, 'matern'), ('f32', 2, 'rbf'), ('f32', 5, 'rbf')])
+def test_score_paths_against_explicit_logdets(dtname, D, kern):
+    """algp_score_paths (a8 / f3, agent.py:386-399: one slogdet of the enlarged covariance per path) against exactly
+    that, in NumPy: dH = H(A u path) - H(A) with a mobile reading at every distinct site of the path; a site that already
+    is a train row gets a second row (cross entry k + sigma_n^2).  Coordinate widths 2..6 cover the three padded widths of
+    the kernel's coordinate loads (2, 4, 8), both kernels and both precisions."""
+    dt = np.float64 if dtname == 'f64' else np.float32
+    rng = np.random.RandomState(D * 7 + (dt == np.float32))
+    n, nA = 260, 110
+    X = rng.uniform(0, 9, (n, D))
+    kid = O.KERNEL_RBF if kern == 'rbf' else O.KERNEL_MATERN15
+    hyp = O.Hypers(np.log(rng.uniform(2.0, 4.0, D)), np.log(0.8), np.log(2e-2), kid)
+    A = np.sort(rng.permutation(n)[:nA])
+    varA = rng.choice([0.01, 1.0], nA)
+    c = _hip.Context(dt)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise, kernel=kid)
+    c.set_pool(X)
+    c.set_train(A, np.zeros(nA), varA)
+    c.factorize()
+    c.set_candidates(np.arange(n), prior_includes_noise=True)
+    c.solve_candidates()
+    mobile_std = 0.7
+    others = np.setdiff1d(np.arange(n), A)
+    paths = np.full((24, 20), -1, dtype=np.int64)
+    want = np.zeros(24)
+    K = O.kernel_matrix(hyp, X) + hyp.noise * np.eye(n)
+    SA = K[np.ix_(A, A)] + np.diag(varA)
+    ldA = np.linalg.slogdet(SA)[1]
+    for p in range(24):
+        L = rng.randint(1, 18)
+        sites = list(rng.permutation(others)[:L])
+        if p % 3 == 0:
+            sites[rng.randint(L)] = int(A[rng.randint(nA)])              # crosses a train site: a second row for it
+        if p % 4 == 0:
+            sites.append(sites[0])                                       # a site crossed twice counts once
+        row = list(sites)
+        row.insert(rng.randint(len(row) + 1), -1)                        # an off-field pose in the middle
+        paths[p, :len(row)] = row
+        uniq = list(dict.fromkeys(int(s) for s in sites))
+        idx = np.r_[A, uniq].astype(int)
+        S = K[np.ix_(idx, idx)] + np.diag(np.r_[varA, np.full(len(uniq), mobile_std ** 2)])
+        want[p] = len(uniq) * O.CONST + 0.5 * (np.linalg.slogdet(S)[1] - ldA)
+    got = c.score_paths(paths, mobile_std)
+    c.close()
+    tol = 1e-9 if dt == np.float64 else 2e-3
+    assert np.max(np.abs(got - want)) < tol * max(1.0, np.max(np.abs(want))), np.max(np.abs(got - want))
