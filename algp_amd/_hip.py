@@ -259,7 +259,7 @@ class Context(object):
         return kept.value
 
     def fit_and_solve(self):
-        """factorize() + solve_candidates() as one overlapped pipeline."""
+        """factorize() + solve_candidates() back to back in one ABI call."""
         self._check(self.lib.algp_fit_and_solve(self.h))
 
     def _get_double(self, fn):

@@ -127,10 +127,9 @@ int algp_factorize_update(algp_ctx* ctx, int64_t* kept_rows);
  * z / MLL terms are computed for THIS context's targets.  Both pools must address the train sites by the same
  * indices.  ALGP_ERR_STATE when the source's factor belongs to another train set or other hyper-parameters.    */
 int algp_factorize_from(algp_ctx* ctx, algp_ctx* src, int64_t* kept_rows);
-/* algp_factorize + algp_solve_candidates as one pipeline: the factorisation runs on a high-priority
- * stream and the candidate solve follows it column block by column block, so the Cholesky's
- * latency-bound panel kernels hide under the solve's GEMMs.  Needs algp_set_train and
- * algp_set_candidates; same results as the two separate calls.                                    */
+/* algp_factorize + algp_solve_candidates back to back in one call (one ABI crossing per planning step; what bench.py's
+ * step uses).  Needs algp_set_train and algp_set_candidates; same results as the two separate calls.  (Round 1 overlapped
+ * the two on separate streams: slower, removed -- the factorisation is now a single dependency-driven launch.)          */
 int algp_fit_and_solve(algp_ctx* ctx);
 int algp_get_logdet(algp_ctx* ctx, double* logdet);          /* log det S                        */
 int algp_get_entropy(algp_ctx* ctx, double* H);              /* N*CONST + 1/2 log det S (utils.py:188) */
@@ -242,7 +241,8 @@ int algp_trsm_right_lt(algp_ctx* ctx, const void* L, int64_t n, const void* B, i
  * returns the number of mismatching outputs (0 expected).                                      */
 int algp_selftest_mfma(algp_ctx* ctx, int* mismatches);
 /* device-resident GEMM timing on pseudo-random operands (no host traffic): average ms per launch
- * of D = C - A B^T (beta_one) or D = -A B^T, m x n x k, kernel variant 0|1, lower tiles only or all. */
+ * of D = C - A B^T (beta_one) or D = -A B^T, m x n x k, lower tiles only or all (`variant` is reserved: the A/B
+ * kernels of round 1 are gone, there is one GEMM kernel).                                              */
 int algp_bench_gemm(algp_ctx* ctx, int64_t m, int64_t n, int64_t k, int variant, int lower_only,
                     int beta_one, int reps, double* ms_per_launch);
 
