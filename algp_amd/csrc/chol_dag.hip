@@ -9,6 +9,7 @@
 //                       (the first to arrive), with no hand-off in between and its CU to itself
 //     TRSM(i,k)         L_ik = S_ik X_kk^T                                   (MFMA tile product, K = 128)
 //     UPD(i,j,k0,k1)    S_ij -= L_i,[k0,k1) L_j,[k0,k1)^T                    (MFMA tile product, K = 128 (k1-k0))
+//     TU(i,k)           TRSM(i,k), then UPD(i,k+1,k,k+1) by the same workgroup: every row's step-to-step recurrence
 // executed by persistent workgroups that draw tasks from ONE ordered list with an atomic ticket.  A task waits
 // (bounded spin on per-tile version counters) until its inputs are final; because the list is a topological
 // order and tickets are handed out in list order, every task's producers are already held by running
@@ -33,13 +34,13 @@
 
 namespace algp {
 
-enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2 };
+enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2, DAG_TU = 3 };
 constexpr int DAG_STRIPS = 4;                                 // row strips of a 128-row tile product on the chain
 constexpr int DAG_TEAM = 1 + DAG_STRIPS;                      // workgroups on the diagonal chain: leader + one helper per strip
 constexpr int DAG_CTRL = 16;                                  // control words
 struct DagTask {
     int type, i, j, kk;                                        // kk = (k0 << 16) | k1
-};
+};                                                             // DAG_TU: TRSM(i,j) and then UPD(i,j+1,j) by the same workgroup
 
 template <typename T>
 struct DagArgs {
@@ -466,6 +467,31 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         const DagTask task = g.tasks[t];
         const int type = task.type, ti = task.i, tj = task.j, k0 = task.kk >> 16, k1 = task.kk & 0xffff;
 
+        if (type == DAG_TU) {
+            // every row's recurrence from one column step to the next: L_ik = S_ik X_kk^T, then S_i,k+1 -= L_ik L_k+1,k^T
+            // (TRSM(i,k+1) needs it).  As two tasks the pair cost two tickets and a hand-off through HBM per step and
+            // was the longest path of the whole graph (76 x 78 us for the last row); one workgroup does both, the
+            // second product reading the tile it has just written.
+            const int k = tj;
+            if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k) : (lane == 1 ? dag_ver(g, k, k) : nullptr),
+                             lane == 0 ? k : k + 1, &s_ok)) break;
+            DAG_TRACE(t, 1);
+            unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
+            dag_tile_op<T>(g, sm.gemm, false, ti, k, k, k + 1);
+            st_trsm += __builtin_amdgcn_s_memrealtime() - tick0;
+            ++st_ntrsm;
+            dag_publish<T>(g, ti, k, k + 1);
+            if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k + 1) : (lane == 1 ? dag_ver(g, k + 1, k) : nullptr),
+                             lane == 0 ? k : k + 1, &s_ok)) break;
+            tick0 = __builtin_amdgcn_s_memrealtime();
+            dag_tile_op<T>(g, sm.gemm, true, ti, k + 1, k, k + 1);
+            st_upd += __builtin_amdgcn_s_memrealtime() - tick0;
+            ++st_steps;
+            DAG_TRACE(t, 2);
+            dag_publish<T>(g, ti, k + 1, k + 1);
+            DAG_TRACE(t, 3);
+            continue;
+        }
         // ---- wait for the inputs: lane l polls dependency l ----
         int ndeps, di = ti, dj = tj, want = 0;
         if (type == DAG_TRSM) {
@@ -534,6 +560,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         int npred;
         bool on_chain = false;
         std::vector<int> succ;
+        std::vector<int> succ_start;                                        // nodes that may start once this one HAS STARTED
     };
     std::vector<Node> nodes;
     std::vector<int> last_writer((size_t)nt * nt, -1), trsm((size_t)nt * nt, -1), diag(nt, -1);
@@ -549,6 +576,13 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     auto edge = [&](int from, int to) {
         if (from < 0) return;
         nodes[from].succ.push_back(to);
+        nodes[to].npred++;
+    };
+    // `to` only needs `from` to have an earlier ticket (it waits for it half-way through, holding its workgroup): in
+    // the simulation it may start as soon as `from` has started
+    auto edge_after_start = [&](int from, int to) {
+        if (from < 0) return;
+        nodes[from].succ_start.push_back(to);
         nodes[to].npred++;
     };
     // durations in microseconds as measured at N = 10 000 (bulk workgroups share a CU's matrix cores in pairs, the
@@ -603,10 +637,22 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             }
         }
         for (int i = k + 3; i < nt; ++i) {
-            const int tr = add(DAG_TRSM, i, k, k, k + 1, D_OP + D_OVH);
+            // TRSM(i,k) and UPD(i,k+1,k) are one ticketed task (DAG_TU): in the simulation the ticketed node is the first
+            // product (L_ik is published when it ends) and the second a continuation that starts when its other inputs
+            // are there.  The ticket is handed out only after the second product's other input, the tile's last update,
+            // has its ticket (edge_after_start), so that everything a task waits for -- at its start or half-way --
+            // is held by a workgroup that is already running: the no-deadlock argument of the header stays intact.
+            const int tr = add(DAG_TU, i, k, k, k + 1, D_OP + D_OVH);
             edge(d, tr);
             edge(last_writer[(size_t)i * nt + k], tr);
             trsm[(size_t)i * nt + k] = tr;
+            edge_after_start(last_writer[(size_t)i * nt + (k + 1)], tr);
+            const int u = add(DAG_CHAIN, i, k + 1, k, k + 1, D_OP + 0.5f * D_OVH);
+            nodes[u].on_chain = true;
+            edge(tr, u);
+            edge(last_writer[(size_t)i * nt + (k + 1)], u);
+            edge(trsm[(size_t)(k + 1) * nt + k], u);
+            last_writer[(size_t)i * nt + (k + 1)] = u;
         }
         auto upd = [&](int i, int j, int k0, int k1) {
             const int u = add(DAG_UPD, i, j, k0, k1, D_OVH + D_OP * (k1 - k0));
@@ -621,7 +667,8 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             const int kf = batched_until(j, W);
             if (k >= kf) {
                 for (int i = j; i < nt; ++i)
-                    if (i > k + 2) upd(i, j, k, k + 1);                      // single step (rows k+1, k+2 are the team's)
+                    if (i > k + 2 && j != k + 1) upd(i, j, k, k + 1);   // single step (rows k+1, k+2 are the team's,
+                                                                             // column k+1 went with the TRSM: DAG_TU)
             } else if ((k + 1) % 4 == 0) {
                 for (int i = j; i < nt; ++i) upd(i, j, k - 3, k + 1);        // batch of four
             }
@@ -640,12 +687,12 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         int v = 0;
         for (int u = 0; u < n; ++u) if (nodes[u].prio > nodes[v].prio) v = u;
         fprintf(stderr, "critical path %.0f us:", nodes[v].prio);
-        float by_type[3] = {0, 0, 0};
+        float by_type[4] = {0, 0, 0, 0};
         int cnt = 0;
         for (;;) {
             by_type[nodes[v].t.type] += nodes[v].dur;
             if (cnt++ < 12 || nodes[v].succ.empty())
-                fprintf(stderr, " %s(%d,%d,%d..%d)", nodes[v].t.type == 0 ? "CHAIN" : nodes[v].t.type == 1 ? "TRSM" : "UPD", nodes[v].t.i, nodes[v].t.j,
+                fprintf(stderr, " %s(%d,%d,%d..%d)", nodes[v].t.type == 0 ? "CHAIN" : nodes[v].t.type == 1 ? "TRSM" : nodes[v].t.type == 2 ? "UPD" : "TU", nodes[v].t.i, nodes[v].t.j,
                         nodes[v].t.kk >> 16, nodes[v].t.kk & 0xffff);
             else if (cnt == 14) fprintf(stderr, " ...");
             if (nodes[v].succ.empty()) break;
@@ -653,7 +700,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             for (int s2 : nodes[v].succ) if (nodes[s2].prio > nodes[b].prio) b = s2;
             v = b;
         }
-        fprintf(stderr, "\n  time on the path by type: chain %.0f trsm %.0f upd %.0f\n", by_type[0], by_type[1], by_type[2]);
+        fprintf(stderr, "\n  time on the path by type: chain/continuations %.0f trsm %.0f upd %.0f trsm+upd %.0f\n", by_type[0], by_type[1], by_type[2], by_type[3]);
     }
     std::vector<float> t_start(n, 0.f);
 #define DAG_SIM_START(v) t_start[v] = now
@@ -669,17 +716,28 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     out.tasks.reserve(n);
     float now = 0;
     int freew = workers - 2 * DAG_TEAM, started = 0;                         // the team and its retired CU neighbours
+    std::vector<int> just_started;
     auto release = [&](int v) {                                              // all inputs of v are there
         if (nodes[v].on_chain) {
             DAG_SIM_START(v);
             running.push(PI(now + nodes[v].dur, v));
             ++started;
+            just_started.push_back(v);
         } else {
             ready.push(PI(nodes[v].prio, v));
         }
     };
+    auto drain_started = [&]() {                                             // edge_after_start successors
+        while (!just_started.empty()) {
+            const int v = just_started.back();
+            just_started.pop_back();
+            for (int s2 : nodes[v].succ_start)
+                if (--nodes[s2].npred == 0) release(s2);
+        }
+    };
     for (int v = 0; v < n; ++v)
         if (nodes[v].npred == 0) release(v);
+    drain_started();
     while (started < n) {
         while (freew > 0 && !ready.empty()) {
             const int v = ready.top().second;
@@ -689,6 +747,8 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             DAG_SIM_START(v);
             running.push(PI(now + nodes[v].dur, v));
             --freew;
+            just_started.push_back(v);
+            drain_started();
         }
         if (running.empty()) break;                                          // cannot happen for a DAG
         now = running.top().first;
@@ -698,6 +758,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             if (!nodes[v].on_chain) ++freew;
             for (int s2 : nodes[v].succ)
                 if (--nodes[s2].npred == 0) release(s2);
+            drain_started();
         }
     }
     out.nt = nt;
