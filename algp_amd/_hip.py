@@ -25,6 +25,7 @@ PROF = dict(kmat=0, gemm_chol=1, gemm_trsm=2, potrf_diag=3, trsv=4, rows=5, scor
             gemm_chol_update=10, chol_dag=11)
 
 _c_ctx = C.c_void_p
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)   # algp_allgather_fn
 _i64p = C.POINTER(C.c_int64)
 _dblp = C.POINTER(C.c_double)
 
@@ -75,7 +76,7 @@ SIGNATURES = {
                                C.c_double, C.c_void_p, C.c_void_p]),
     'algp_trsm_right_lt': (C.c_int, [_c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     'algp_selftest_mfma': (C.c_int, [_c_ctx, C.POINTER(C.c_int)]),
-    'algp_bench_gemm': (C.c_int, [_c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _dblp]),
+    'algp_bench_gemm': (C.c_int, [_c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _dblp]),
     'algp_sync': (C.c_int, [_c_ctx]),
     'algp_device_bytes': (C.c_int64, [_c_ctx]),
     'algp_prof_enable': (C.c_int, [_c_ctx, C.c_int]),
@@ -85,7 +86,12 @@ SIGNATURES = {
     'algp_score_paths': (C.c_int, [_c_ctx, _i64p, C.c_int, C.c_int, C.c_double, _dblp]),
     'algp_comm_unique_id': (C.c_int, [C.c_void_p]),
     'algp_comm_init': (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_void_p]),
+    'algp_comm_init_host': (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'algp_comm_destroy': (C.c_int, [_c_ctx]),
+    'algp_debug_first_max': (C.c_int, [_c_ctx, _dblp, C.c_int, _dblp]),
+    'algp_debug_fail_next_pick': (C.c_int, [_c_ctx, C.c_int]),
+    'algp_debug_set_trsm_chunks': (C.c_int, [_c_ctx, C.c_int]),
+    'algp_debug_counter': (C.c_int64, [_c_ctx, C.c_int]),
     'algp_greedy_sharded': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_int, _i64p, _dblp]),
 }
 
@@ -399,8 +405,44 @@ class Context(object):
             raise ValueError('unique_id must be the 128 bytes of comm_unique_id()')
         self._check(self.lib.algp_comm_init(self.h, int(nranks), int(rank), C.create_string_buffer(unique_id, 128)))
 
+    def comm_init_host(self, nranks, rank, all_gather):
+        """The sharded greedy loop over a transport the caller owns: all_gather(send: bytes) -> bytes must return the
+        concatenation, in rank order, of what every rank passed (algp_comm_init_host)."""
+        def tramp(_user, send, recv, nbytes):
+            try:
+                out = all_gather(C.string_at(send, nbytes))
+                if len(out) != nbytes * int(nranks):
+                    return 2
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:                                     # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._gather_cb = ALLGATHER_FN(tramp)                     # keep the trampoline alive as long as the ctx uses it
+        self._check(self.lib.algp_comm_init_host(self.h, int(nranks), int(rank), C.cast(self._gather_cb, C.c_void_p), None))
+
     def comm_destroy(self):
         self._check(self.lib.algp_comm_destroy(self.h))
+        self._gather_cb = None
+
+    def debug_first_max(self, triples):
+        """first_max_kernel on a fabricated (nranks, 3) buffer -> (utility, pool index, owner, status, failing rank)."""
+        t = np.ascontiguousarray(triples, dtype=np.float64).reshape(-1, 3)
+        out = np.empty(5, dtype=np.float64)
+        self._check(self.lib.algp_debug_first_max(self.h, t.ctypes.data_as(_dblp), len(t), out.ctypes.data_as(_dblp)))
+        return out
+
+    def debug_fail_next_pick(self, code):
+        self._check(self.lib.algp_debug_fail_next_pick(self.h, int(code)))
+
+    def set_trsm_chunks(self, chunks):
+        """Row-chunk streams of the candidate solve (1..4; 0 = default).  Same results for every setting."""
+        self._check(self.lib.algp_debug_set_trsm_chunks(self.h, int(chunks)))
+
+    def sync_count(self):
+        """Stream synchronisations the library has issued for this context so far."""
+        return int(self.lib.algp_debug_counter(self.h, 0))
 
     def greedy_sharded(self, criterion, static_std, mobile_std, k, want_utilities=False):
         """k picks over the candidate shards of all ranks (one RCCL all-gather per pick inside the library)."""
@@ -465,9 +507,9 @@ class Context(object):
         self._check(self.lib.algp_selftest_mfma(self.h, C.byref(v)))
         return v.value
 
-    def bench_gemm(self, m, n, k, variant=1, lower_only=False, beta_one=True, reps=5):
+    def bench_gemm(self, m, n, k, lower_only=False, beta_one=True, reps=5):
         ms = C.c_double()
-        self._check(self.lib.algp_bench_gemm(self.h, m, n, k, int(variant), int(bool(lower_only)), int(bool(beta_one)),
+        self._check(self.lib.algp_bench_gemm(self.h, m, n, k, int(bool(lower_only)), int(bool(beta_one)),
                                              int(reps), C.byref(ms)))
         return ms.value
 

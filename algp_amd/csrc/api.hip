@@ -1,6 +1,7 @@
 // api.hip -- extern "C" entry points of libalgp_hip.so (declared in include/algp_hip.h) and the
-// host-side orchestration of the device kernels.  No torch types, no CPU arithmetic fallback:
-// every numeric result comes from the HIP kernels in this directory.
+// host-side orchestration of the device kernels.  No torch types, no CPU fallback: every matrix, vector and
+// per-candidate quantity comes from the HIP kernels in this directory; what the host computes is bookkeeping
+// (index maps, the mean of the targets) and O(1) scalar combinations of values the kernels returned.
 #include <limits.h>
 #include <math.h>
 #include <string.h>
@@ -175,6 +176,7 @@ KmatSrc make_src(algp_ctx* c) {
 
 int sync(algp_ctx* c) {
     ALGP_HIP(hipStreamSynchronize(c->stream));
+    c->n_syncs++;
     return ALGP_OK;
 }
 
@@ -1005,7 +1007,9 @@ struct Impl {
         return ALGP_OK;
     }
 
-    static int scores(algp_ctx* c, int criterion, double static_std, double mobile_std, void* out, int out_is_device) {
+    // utilities of every row into `dst` (device; null = c->scores), stream-ordered, no synchronisation of its own for the
+    // entropy criterion (the MI terms are assembled through the host)
+    static int scores_enqueue(algp_ctx* c, int criterion, double static_std, double mobile_std, double* dst) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "scores: call algp_solve_candidates first");
         if (!c->prior_noise) return fail(c, ALGP_ERR_STATE, "scores: candidates were set with predictive semantics");
         ALGP_TRY(flush_lazy(c));
@@ -1022,18 +1026,21 @@ struct Impl {
         } else if (criterion != ALGP_CRIT_ENTROPY) {
             return fail(c, ALGP_ERR_BAD_ARG, "unknown criterion");
         }
-        double* dst = out_is_device ? (double*)out : (double*)c->scores.p;
+        if (!dst) dst = (double*)c->scores.p;
         ALGP_TRY(score_launch<T>(c, c->M, (const int*)c->ckind.p, (const unsigned char*)c->alive.p, (const T*)c->dstat.p,
                                  ss, delta, extra_dev, dst));
         // entropy utilities of up-to-date rows: from here on c->scores can serve as upper bounds (lazy greedy)
         c->bounds_valid = criterion == ALGP_CRIT_ENTROPY;
         c->lazy_ss = ss;
         c->lazy_delta = delta;
-        if (out_is_device) {
+        if (dst != (double*)c->scores.p)
             ALGP_HIP(hipMemcpyAsync(c->scores.p, dst, sizeof(double) * c->M, hipMemcpyDeviceToDevice, c->stream));
-        } else if (out) {
+        return ALGP_OK;
+    }
+    static int scores(algp_ctx* c, int criterion, double static_std, double mobile_std, void* out, int out_is_device) {
+        ALGP_TRY(scores_enqueue(c, criterion, static_std, mobile_std, out_is_device ? (double*)out : nullptr));
+        if (!out_is_device && out)
             ALGP_HIP(hipMemcpyAsync(out, c->scores.p, sizeof(double) * c->M, hipMemcpyDeviceToHost, c->stream));
-        }
         return sync(c);
     }
 
@@ -1107,15 +1114,16 @@ struct Impl {
 
     // Make `pool_idx` static-sampled.  Only the pick is recorded (its row of V^T, its scale); the other rows
     // of V^T / dstat catch up on demand (lazy_refresh_kernel) -- before anything reads the full state
-    // (flush_lazy) or, in best_candidate, only the rows that can still win.
-    static int commit_pick(algp_ctx* c, int64_t pool_idx, double static_std, double mobile_std) {
+    // (flush_lazy) or, while the next pick is resolved, only the rows that can still win.
+    // commit_enqueue: everything stream-ordered, nothing read back (the winner's statistic d_c and the scale of the
+    // appended row stay on the device, in scal[SC_COMMIT..]); the local / remote decision is the host's, from the pool
+    // index it already holds.
+    static int commit_enqueue(algp_ctx* c, int64_t pool_idx, double ss, double delta) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "commit_pick: call algp_solve_candidates first");
         if (pool_idx < 0 || pool_idx >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: index outside the pool");
         if ((int64_t)c->picks.size() >= MAX_APPEND) return fail(c, ALGP_ERR_STATE, "commit_pick: append capacity exhausted; re-factorize");
         for (auto& pk : c->picks)
             if (pk.pool_idx == pool_idx) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: site already static-sampled");
-        const double ss = static_std * static_std, sm = mobile_std * mobile_std;
-        const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
         const int in_train = c->pos_in_train[pool_idx] >= 0 ? 1 : 0;
         const int64_t local = c->cand_pos[pool_idx];
         const int64_t ldv = c->ldv, ncols = c->ncols;
@@ -1130,36 +1138,47 @@ struct Impl {
             ALGP_TRY(remote_row(c, pool_idx, in_train));
             dsrc = remote_slots(c).dstat;
         }
-        // scale of the appended row, pick record, winner retired: on the device; ONE read-back (d_c, scale) per pick
         double* sc = (double*)c->scal.p;
         ALGP_HIP(hipMemcpyAsync(p(c->prevrows) + (int64_t)q * ldv, c->lrow.p, sizeof(T) * ldv, hipMemcpyDeviceToDevice, c->stream));
         ALGP_TRY(commit_finalize_launch<T>(c, dsrc, in_train, ss, delta, (LazyPick*)c->lazypicks.p + q, pool_idx, ncols,
                                            local >= 0 ? (unsigned char*)c->alive.p + local : nullptr,
                                            local >= 0 ? (double*)c->scores.p + local : nullptr, sc + SC_COMMIT));
-        double host[2];
-        ALGP_HIP(hipMemcpyAsync(host, sc + SC_COMMIT, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        ALGP_TRY(sync(c));
-        const double scale = host[1];
-        if (!(scale == scale) || isinf(scale))
-            return fail(c, ALGP_ERR_NOT_PD, "commit_pick: posterior variance of the pick is not positive");
         PickRec pr;
         pr.pool_idx = pool_idx;
         pr.in_train = in_train;
-        pr.scale = scale;
         c->picks.push_back(pr);
         c->ncols = ncols + 1;
         c->lazy_stale = true;
         return ALGP_OK;
     }
+    // the ABI's algp_commit_pick: any pool index the caller names, so the scale is read back and checked (a pick the
+    // library resolved itself has a finite utility, which already implies a positive variance under the square root)
+    static int commit_pick(algp_ctx* c, int64_t pool_idx, double static_std, double mobile_std) {
+        const double ss = static_std * static_std, sm = mobile_std * mobile_std;
+        const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
+        const bool was_stale = c->lazy_stale;
+        ALGP_TRY(commit_enqueue(c, pool_idx, ss, delta));
+        double host[2];
+        ALGP_HIP(hipMemcpyAsync(host, (double*)c->scal.p + SC_COMMIT, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        ALGP_TRY(sync(c));
+        const double scale = host[1];
+        if (!(scale == scale) || isinf(scale)) {
+            c->picks.pop_back();                                  // the rows never see the pick: its record is not counted
+            c->ncols -= 1;
+            c->lazy_stale = was_stale;
+            return fail(c, ALGP_ERR_NOT_PD, "commit_pick: posterior variance of the pick is not positive");
+        }
+        return ALGP_OK;
+    }
 
     // ---- lazy greedy (entropy criterion, picks only): see lazy_refresh_kernel in vecops.hip ----
-    static int lazy_launch(algp_ctx* c, int mode, int64_t pos, double ss, double delta) {
+    static int lazy_launch(algp_ctx* c, int mode, int64_t pos, double ss, double delta, const int64_t* pos_dev = nullptr) {
         return lazy_refresh_launch<T>(c, c->M, mode, pos, (const LazyPick*)c->lazypicks.p, (int)c->picks.size(),
                                       (const int*)c->ckind.p, (const int64_t*)c->Cidx.p, (const T*)c->Xs.p,
                                       c->pool_is_cov ? (const T*)c->Cp.p : nullptr, c->n_pool, c->hyp.DP, c->hyp.kernel,
                                       (T)c->hyp.outputscale, (T)c->hyp.noise, p(c->prevrows), c->ldv, p(c->Vt),
                                       p(c->dstat), (int*)c->fresh.p, (const unsigned char*)c->alive.p,
-                                      (double*)c->scores.p, ss, delta);
+                                      (double*)c->scores.p, ss, delta, pos_dev);
     }
     // after a candidate solve: no picks, every row current, no bounds
     static int reset_lazy(algp_ctx* c) {
@@ -1178,24 +1197,45 @@ struct Impl {
         return ALGP_OK;
     }
 
-    // The best local candidate under the current state.  Entropy criterion: c->scores holds, per row, the
-    // utility as of the picks applied to that row -- an upper bound of the current one -- and only the rows
-    // that can still win are brought up to date.  MI: full scoring (its complement terms change with every pick).
+    // The best local candidate under the current state, left ON THE DEVICE (scal[SC_AMAXV], scal[SC_AMAXI]) by one
+    // stream-ordered chain with no host decision inside.  Entropy criterion: c->scores holds, per row, the utility as
+    // of the picks applied to that row -- an upper bound of the current one (submodularity).  argmax -> refresh of that
+    // row (its now-exact utility is the threshold) -> refresh of every stale row whose bound reaches the threshold ->
+    // argmax: every row that is still stale now scores below a fresh one, so the second argmax is a fresh row and the
+    // true first maximum.  (Only a NaN utility breaks that argument; the status word of the pick then asks for one more
+    // round.)  The kernels take the row from the device, and a refresh of an up-to-date row is a no-op.
+    static int enqueue_local_best(algp_ctx* c, double ss, double delta) {
+        double* sc = (double*)c->scal.p;
+        int64_t* pos_dev = (int64_t*)(sc + SC_AMAXI);
+        if (c->lazy_stale) {
+            ALGP_TRY(argmax_launch(c, (const double*)c->scores.p, c->M, sc + SC_AMAXV, pos_dev));
+            ALGP_TRY(lazy_launch(c, 0, 0, ss, delta, pos_dev));
+            ALGP_TRY(lazy_launch(c, 1, 0, ss, delta, pos_dev));
+        }
+        return argmax_launch(c, (const double*)c->scores.p, c->M, sc + SC_AMAXV, pos_dev);
+    }
+    // c->scores must hold bounds for (ss, delta): otherwise (first pick after a solve, MI criterion, lazy greedy
+    // switched off) every row is scored, which also brings every row up to date
+    static int ensure_bounds(algp_ctx* c, int criterion, double static_std, double mobile_std, double ss, double delta) {
+        static const bool lazy_on = !(getenv("ALGP_LAZY_GREEDY") && atoi(getenv("ALGP_LAZY_GREEDY")) == 0);
+        if (criterion != ALGP_CRIT_ENTROPY || !lazy_on || !c->bounds_valid || c->lazy_ss != ss || c->lazy_delta != delta)
+            return scores_enqueue(c, criterion, static_std, mobile_std, nullptr);
+        return ALGP_OK;
+    }
+
+    // algp_best_candidate: the local first maximum, one read-back (value, position, how many picks its row has seen)
     static int best_candidate(algp_ctx* c, int criterion, double static_std, double mobile_std, int64_t* local_pos,
                               int64_t* pool_idx, double* value) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "best_candidate: call algp_solve_candidates first");
         if (c->M == 0) return fail(c, ALGP_ERR_BAD_ARG, "best_candidate: empty candidate set");
         const double ss = static_std * static_std, sm = mobile_std * mobile_std;
         const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
-        static const bool lazy_on = !(getenv("ALGP_LAZY_GREEDY") && atoi(getenv("ALGP_LAZY_GREEDY")) == 0);
-        if (criterion != ALGP_CRIT_ENTROPY || !lazy_on || !c->bounds_valid || c->lazy_ss != ss || c->lazy_delta != delta)
-            ALGP_TRY(scores(c, criterion, static_std, mobile_std, nullptr, 0));      // flushes, scores every row
-        int64_t pos;
-        double val;
-        for (;;) {
-            // argmax + how many picks its row has seen, ONE read-back per round
-            double* sc = (double*)c->scal.p;
-            ALGP_TRY(argmax_launch(c, (const double*)c->scores.p, c->M, sc + SC_AMAXV, (int64_t*)(sc + SC_AMAXI)));
+        ALGP_TRY(ensure_bounds(c, criterion, static_std, mobile_std, ss, delta));
+        double* sc = (double*)c->scal.p;
+        int64_t pos = -1;
+        double val = -INFINITY;
+        for (int round = 0; round < 8; ++round) {
+            ALGP_TRY(enqueue_local_best(c, ss, delta));
             ALGP_TRY(fresh_at_launch(c, (const int*)c->fresh.p, (const int64_t*)(sc + SC_AMAXI), sc + SC_AMAXF));
             double host[3];
             ALGP_HIP(hipMemcpyAsync(host, sc + SC_AMAXV, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1205,8 +1245,6 @@ struct Impl {
             val = host[0];
             if (pos < 0 || !c->lazy_stale) break;                 // all NaN, or nothing committed since the full scoring
             if ((int)host[2] >= (int)c->picks.size()) break;      // the maximum is an up-to-date row: it wins
-            ALGP_TRY(lazy_launch(c, 0, pos, ss, delta));          // the best bound becomes a true value ...
-            ALGP_TRY(lazy_launch(c, 1, pos, ss, delta));          // ... and every bound reaching it is resolved
         }
         if (local_pos) *local_pos = pos;
         if (pool_idx) *pool_idx = pos >= 0 ? c->cand_idx[pos] : -1;
@@ -1214,8 +1252,62 @@ struct Impl {
         return ALGP_OK;
     }
 
+    // k picks of the entropy criterion, on one rank or over the candidate shards of several (agent.py:313-354 with the
+    // loop over candidates cut into shards): per pick ONE host round trip -- the 40-byte record (utility, pool index,
+    // owner, status, failing rank) that comm_pick_exchange reads back after [local best on the device -> pack ->
+    // all-gather of the triples -> first maximum in rank order].  The commit of the winner is enqueued behind it and
+    // not waited for (the next pick's kernels, or whatever the caller does next, are stream-ordered after it).
+    // Nothing rank-local returns before the exchange: a failure becomes this rank's status word, every rank sees it in
+    // the same gather and every rank returns it -- nobody is left waiting in a collective.
+    static int greedy_picks(algp_ctx* c, double static_std, double mobile_std, int k, int64_t* picks_out, double* ut_out) {
+        const double ss = static_std * static_std, sm = mobile_std * mobile_std;
+        const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
+        double* sc = (double*)c->scal.p;
+        for (int pck = 0; pck < k; ++pck) {
+            double rec[5];
+            for (int round = 0;; ++round) {
+                int st = ALGP_OK;
+                if (c->debug_fail_next_pick) {
+                    st = fail(c, c->debug_fail_next_pick, "greedy: failure injected by algp_debug_fail_next_pick");
+                    c->debug_fail_next_pick = 0;
+                } else if (!c->solved) {
+                    st = fail(c, ALGP_ERR_STATE, "greedy: call algp_solve_candidates first");
+                } else if (!c->prior_noise) {
+                    st = fail(c, ALGP_ERR_STATE, "greedy: candidates were set with predictive semantics");
+                }
+                if (st == ALGP_OK && c->M > 0) st = ensure_bounds(c, ALGP_CRIT_ENTROPY, static_std, mobile_std, ss, delta);
+                if (st == ALGP_OK && c->M > 0) st = enqueue_local_best(c, ss, delta);
+                const bool have = st == ALGP_OK && c->M > 0;             // an empty shard offers nothing; that is not an error
+                const std::string local_err = c->err;
+                ALGP_TRY(comm_pick_exchange(c, have ? sc + SC_AMAXV : nullptr, have ? (const int64_t*)(sc + SC_AMAXI) : nullptr,
+                                            (const int64_t*)c->Cidx.p, c->lazy_stale ? (const int*)c->fresh.p : nullptr,
+                                            (int)c->picks.size(), st, rec));
+                if (rec[3] >= 2.0) {
+                    const int code = (int)rec[3];
+                    if (st != ALGP_OK) return fail(c, st, local_err);
+                    return fail(c, code, "greedy_sharded: rank " + std::to_string((int)rec[4]) + " failed with error " +
+                                             std::to_string(code) + " while resolving its best candidate; no rank committed pick " +
+                                             std::to_string(pck));
+                }
+                if (rec[3] == 0.0) break;
+                if (round == 8) return fail(c, ALGP_ERR_STATE, "greedy: the best candidate could not be resolved (NaN utilities)");
+            }
+            if (rec[1] < 0) return fail(c, ALGP_ERR_STATE, "greedy: no candidate left on any rank");
+            if (!(rec[0] > -INFINITY))
+                return fail(c, ALGP_ERR_STATE, "greedy: every remaining candidate is already static-sampled (a further pick would "
+                                               "re-sample a static site)");
+            const int64_t pool_idx = (int64_t)rec[1];
+            if (picks_out) picks_out[pck] = pool_idx;
+            if (ut_out) ut_out[pck] = rec[0];
+            ALGP_TRY(commit_enqueue(c, pool_idx, ss, delta));
+        }
+        return ALGP_OK;
+    }
+
     static int greedy(algp_ctx* c, int criterion, double static_std, double mobile_std, int k, const int64_t* forced,
                       int64_t* picks_out, double* ut_out) {
+        if (!ut_out && !forced && criterion == ALGP_CRIT_ENTROPY && !c->comm && !c->host_gather)
+            return greedy_picks(c, static_std, mobile_std, k, picks_out, nullptr);
         for (int pck = 0; pck < k; ++pck) {
             int64_t pool_idx;
             if (ut_out || forced) {
@@ -1269,26 +1361,6 @@ struct Impl {
                                       mobile_std * mobile_std, (double*)c->hostStage.p));
         ALGP_HIP(hipMemcpyAsync(dH, c->hostStage.p, sizeof(double) * npaths, hipMemcpyDeviceToHost, c->stream));
         return sync(c);
-    }
-
-    // k picks over candidate shards on several ranks: per pick the local best (lazily resolved), ONE all-gather of the
-    // (utility, pool index) pairs on the stream, first maximum in rank order, every rank commits the winner
-    // (agent.py:313-354 with the loop over candidates cut into shards)
-    static int greedy_sharded(algp_ctx* c, double static_std, double mobile_std, int k, int64_t* picks_out, double* ut_out) {
-        double* sc = (double*)c->scal.p;
-        for (int pck = 0; pck < k; ++pck) {
-            int64_t pos;
-            ALGP_TRY(best_candidate(c, ALGP_CRIT_ENTROPY, static_std, mobile_std, &pos, nullptr, nullptr));
-            // the argmax kernel's result is still on the device (SC_AMAXV / SC_AMAXI): pack, gather, reduce there
-            double win[3];
-            ALGP_TRY(comm_gather_winner(c, sc + SC_AMAXV, (const int64_t*)(sc + SC_AMAXI), (const int64_t*)c->Cidx.p, win));
-            if (win[1] < 0) return fail(c, ALGP_ERR_STATE, "greedy_sharded: no rank has a candidate left");
-            const int64_t pool_idx = (int64_t)win[1];
-            if (picks_out) picks_out[pck] = pool_idx;
-            if (ut_out) ut_out[pck] = win[0];
-            ALGP_TRY(commit_pick(c, pool_idx, static_std, mobile_std));
-        }
-        return ALGP_OK;
     }
 
     static int mll_grad(algp_ctx* c, double* grad_out) {
@@ -1628,6 +1700,38 @@ int algp_comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128) 
     if (nranks < 1 || rank < 0 || rank >= nranks || !unique_id128) return fail(c, ALGP_ERR_BAD_ARG, "comm_init: bad arguments");
     return comm_init(c, nranks, rank, unique_id128);
 }
+int algp_comm_init_host(algp_ctx* c, int nranks, int rank, algp_allgather_fn fn, void* user) {
+    CHECK_CTX(c);
+    if (nranks < 1 || rank < 0 || rank >= nranks || !fn) return fail(c, ALGP_ERR_BAD_ARG, "comm_init_host: bad arguments");
+    hipStreamSynchronize(c->stream);
+    return comm_init_host(c, nranks, rank, fn, user);
+}
+int algp_debug_first_max(algp_ctx* c, const double* triples, int nranks, double out5[5]) {
+    CHECK_CTX(c);
+    if (!triples || nranks < 1 || nranks > 4096 || !out5) return fail(c, ALGP_ERR_BAD_ARG, "debug_first_max: bad arguments");
+    return comm_debug_first_max(c, triples, nranks, out5);
+}
+int64_t algp_debug_counter(algp_ctx* c, int which) {
+    if (!c) return -1;
+    return which == 0 ? c->n_syncs : -1;
+}
+int algp_debug_set_trsm_chunks(algp_ctx* c, int chunks) {
+    CHECK_CTX(c);
+    if (chunks < 0 || chunks > 4) return fail(c, ALGP_ERR_BAD_ARG, "debug_set_trsm_chunks: 0 (default) .. 4");
+    hipStreamSynchronize(c->stream);
+    if (chunks == 0) {
+        const char* e = getenv("ALGP_TRSM_CHUNKS");
+        chunks = e ? atoi(e) : 3;
+    }
+    c->trsm_chunks = chunks;
+    return ALGP_OK;
+}
+int algp_debug_fail_next_pick(algp_ctx* c, int code) {
+    CHECK_CTX(c);
+    if (code != 0 && (code < 2 || code > ALGP_ERR_NO_DEVICE)) return fail(c, ALGP_ERR_BAD_ARG, "debug_fail_next_pick: an ALGP_ERR_* code >= 2, or 0");
+    c->debug_fail_next_pick = code;
+    return ALGP_OK;
+}
 int algp_comm_destroy(algp_ctx* c) {
     CHECK_CTX(c);
     hipStreamSynchronize(c->stream);
@@ -1641,8 +1745,8 @@ int algp_greedy_sharded(algp_ctx* c, int criterion, double static_std, double mo
     if (criterion != ALGP_CRIT_ENTROPY)
         return fail(c, ALGP_ERR_BAD_ARG, "greedy_sharded: only the entropy criterion shards (the MI criterion needs the "
                                          "pool-wide complement on one GPU: use algp_greedy)");
-    if (!c->comm) return fail(c, ALGP_ERR_STATE, "greedy_sharded: call algp_comm_init first");
-    FINISH(c, DISPATCH(c, greedy_sharded(c, static_std, mobile_std, k, picks_out, utilities_out)));
+    if (!c->comm && !c->host_gather) return fail(c, ALGP_ERR_STATE, "greedy_sharded: call algp_comm_init (or algp_comm_init_host) first");
+    FINISH(c, DISPATCH(c, greedy_picks(c, static_std, mobile_std, k, picks_out, utilities_out)));
 }
 
 int algp_entropy_from_cov(algp_ctx* c, const void* cov, int64_t k, double* H) {
@@ -1689,14 +1793,14 @@ int algp_selftest_mfma(algp_ctx* c, int* mismatches) {
     return Impl<double>::selftest(c, mismatches);
 }
 
-int algp_bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lower_only, int beta_one, int reps,
+int algp_bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int lower_only, int beta_one, int reps,
                     double* ms) {
     CHECK_CTX(c);
     if (!ms || m <= 0 || n <= 0 || k <= 0 || reps <= 0) return fail(c, ALGP_ERR_BAD_ARG, "bench_gemm: bad arguments");
     const bool was = c->prof_on;
     c->prof_on = false;
-    int rc = c->dtype == ALGP_F64 ? bench_gemm<double>(c, m, n, k, variant, lower_only, beta_one, reps, ms)
-                                  : bench_gemm<float>(c, m, n, k, variant, lower_only, beta_one, reps, ms);
+    int rc = c->dtype == ALGP_F64 ? bench_gemm<double>(c, m, n, k, lower_only, beta_one, reps, ms)
+                                  : bench_gemm<float>(c, m, n, k, lower_only, beta_one, reps, ms);
     c->prof_on = was;
     return rc;
 }

@@ -38,10 +38,9 @@ struct Hypers {
     bool set = false;
 };
 
-struct PickRec {           // one committed greedy pick (needed to extend a remote winner's row)
+struct PickRec {           // one committed greedy pick, host side (the device keeps a LazyPick with the row's scale)
     int64_t pool_idx;
     int in_train;          // winner was a mobile-sampled train site (rank-1 noise change)
-    double scale;          // 1/lambda (append) or sqrt(-gamma) (noise change)
 };
 
 struct DagCache {          // device copy of one task list of the dependency-driven Cholesky (chol_dag.hip)
@@ -142,10 +141,15 @@ struct algp_ctx {
     bool vt_has_extra = false;
     int64_t kept_cols_last = 0;
 
-    // multi-GPU: RCCL communicator of the sharded greedy loop (comm.hip), null until algp_comm_init
+    // multi-GPU: transport of the sharded greedy loop's one all-gather (comm.hip): an RCCL communicator
+    // (algp_comm_init), a caller-supplied host all-gather (algp_comm_init_host), or neither (one rank)
     void* comm = nullptr;
+    algp_allgather_fn host_gather = nullptr;
+    void* host_gather_user = nullptr;
     int comm_nranks = 1, comm_rank = 0;
-    algp::DevBuf commbuf;    // [own pair | gathered pairs | winner]
+    algp::DevBuf commbuf;    // [own triple | gathered triples | winner record]
+    int64_t n_syncs = 0;     // stream synchronisations issued by the library (algp_debug_counter)
+    int debug_fail_next_pick = 0;   // algp_debug_fail_next_pick: error code this rank reports in its next pick
 
     // scratch for auxiliary factorizations (entropy_from_cov, set entropies, MI terms, posterior cov)
     algp::DevBuf auxA, auxInv, auxW, auxIdx, auxVar, auxD, hostStage;
@@ -244,7 +248,10 @@ int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet
 int comm_unique_id(void* out128, std::string* why);
 int comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128);
 void comm_destroy(algp_ctx* c);
-int comm_gather_winner(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev, double* winner3);
+int comm_init_host(algp_ctx* c, int nranks, int rank, algp_allgather_fn fn, void* user);
+int comm_pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev,
+                       const int* fresh_dev, int npicks, int status, double* rec5);
+int comm_debug_first_max(algp_ctx* c, const double* triples, int nranks, double* out5);
 void dag_release(algp_ctx* c);   // frees the cached task lists of the dependency-driven Cholesky
 // Cholesky of the npad x npad matrix A (ld), inverse diagonal blocks to invD (one dependency-driven launch, or the
 // blocked right-looking launch sequence for very small / very large matrices)
@@ -278,7 +285,7 @@ int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int6
 template <typename T>
 int test_mfma_launch(algp_ctx* c, int* mismatches_dev);
 template <typename T>
-int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lower_only, int beta_one, int reps,
+int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int lower_only, int beta_one, int reps,
                double* ms_out);
 
 }  // namespace algp

@@ -279,7 +279,7 @@ template int test_mfma_launch<float>(algp_ctx*, int*);
 
 
 // ---------------------------------------------------------------------------------------------
-// device-resident GEMM benchmark (A/B of kernel variants in one process, random operands)
+// device-resident GEMM benchmark (pseudo-random operands, no host traffic)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void fill_random_kernel(T* p, int64_t n, unsigned seed) {
@@ -291,7 +291,7 @@ __global__ void fill_random_kernel(T* p, int64_t n, unsigned seed) {
 }
 
 template <typename T>
-int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lower_only, int beta_one, int reps,
+int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int lower_only, int beta_one, int reps,
                double* ms_out) {
     DevBuf a, b, cc;
     int rc = ensure(c, a, sizeof(T) * m * k);
@@ -301,7 +301,6 @@ int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lo
     hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, c->cur, (T*)a.p, m * k, 1u);
     hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, c->cur, (T*)b.p, n * k, 2u);
     hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->cur, (T*)cc.p, m * n, 3u);
-    (void)variant;                                                 // reserved (round 1's A/B kernels are gone)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -324,7 +323,7 @@ int bench_gemm(algp_ctx* c, int64_t m, int64_t n, int64_t k, int variant, int lo
     c->dev_bytes -= (int64_t)(a.cap + b.cap + cc.cap);
     return rc;
 }
-template int bench_gemm<double>(algp_ctx*, int64_t, int64_t, int64_t, int, int, int, int, double*);
-template int bench_gemm<float>(algp_ctx*, int64_t, int64_t, int64_t, int, int, int, int, double*);
+template int bench_gemm<double>(algp_ctx*, int64_t, int64_t, int64_t, int, int, int, double*);
+template int bench_gemm<float>(algp_ctx*, int64_t, int64_t, int64_t, int, int, int, double*);
 
 }  // namespace algp

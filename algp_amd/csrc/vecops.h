@@ -23,12 +23,13 @@ template <typename T>
 int gather_rows_launch(algp_ctx* c, const T* src, int64_t lds, const int64_t* src_row, T* dst, int64_t ldd, int64_t nrows,
                        int64_t ncols, const int64_t* lrow = nullptr, const T* lscale = nullptr, const T* Lb = nullptr,
                        int64_t ldl = 0);
-// lazy greedy refresh (vecops.hip): mode 0 = row pos, 1 = stale rows whose bound reaches scores[pos], 2 = all stale
+// lazy greedy refresh (vecops.hip): mode 0 = row pos, 1 = stale rows whose bound reaches scores[pos], 2 = all stale;
+// pos_dev != null: the row index is read from the device (what an argmax kernel left there; < 0 = nothing to do)
 template <typename T>
 int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const LazyPick* picks, int npicks, const int* ckind,
                         const int64_t* cidx, const T* Xs, const T* Cp, int64_t n_pool, int DP, int kernel, T os, T noise,
                         const T* prevrows, int64_t ldv, T* Vt, T* dstat, int* fresh, const unsigned char* alive,
-                        double* scores, double ss, double delta);
+                        double* scores, double ss, double delta, const int64_t* pos_dev = nullptr);
 // best_path block scoring: dH of every path from the resident rows of V^T (one workgroup per path, <= 64 sites each)
 template <typename T>
 int path_score_launch(algp_ctx* c, const int64_t* cpos, const int64_t* lpos, int npaths, int maxlen, const int64_t* cidx,

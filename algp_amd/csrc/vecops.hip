@@ -370,9 +370,12 @@ template int gather_rows_launch<float>(algp_ctx*, const float*, int64_t, const i
 // instead of a sweep over all M rows.
 //   mode 0: row `pos` only (grid = 1 block)   mode 1: alive stale rows with scores >= scores[pos]
 //   mode 2: every stale row (flush before anything reads the full state)
+// pos_dev != null: the row is the one an argmax kernel has just left on the device (*pos_dev; < 0 = no row, nothing to
+// do), so that argmax -> refresh -> refresh -> argmax is one stream-ordered chain without a host round trip.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DP>
-__global__ __launch_bounds__(256) void lazy_refresh_kernel(int64_t M, int mode, int64_t pos, const LazyPick* picks,
+__global__ __launch_bounds__(256) void lazy_refresh_kernel(int64_t M, int mode, int64_t pos, const int64_t* pos_dev,
+                                                           const LazyPick* picks,
                                                            int npicks, const int* ckind, const int64_t* cidx,
                                                            const T* Xs, const T* Cp, int64_t n_pool, int kernel, T os,
                                                            T noise, const T* prevrows, int64_t ldv, T* Vt, T* dstat,
@@ -381,6 +384,10 @@ __global__ __launch_bounds__(256) void lazy_refresh_kernel(int64_t M, int mode, 
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
+    if (pos_dev) {
+        pos = *pos_dev;
+        if (pos < 0 && mode != 2) return;
+    }
     const double thr = (mode == 1) ? scores[pos] : 0.0;        // row pos is up to date in mode 1: never rewritten here
     for (int64_t j0 = wave; j0 < M; j0 += nw) {
         int64_t j = j0;
@@ -418,15 +425,15 @@ template <typename T>
 int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const LazyPick* picks, int npicks, const int* ckind,
                         const int64_t* cidx, const T* Xs, const T* Cp, int64_t n_pool, int DP, int kernel, T os, T noise,
                         const T* prevrows, int64_t ldv, T* Vt, T* dstat, int* fresh, const unsigned char* alive,
-                        double* scores, double ss, double delta) {
+                        double* scores, double ss, double delta, const int64_t* pos_dev) {
     if (M <= 0 || npicks <= 0) return ALGP_OK;
     int64_t g = (mode == 0) ? 1 : (M + 3) / 4;
     if (g > 65536) g = 65536;
     ProfScope ps(c, ALGP_PROF_ROWS, 0.0, 13.0 * M);
     dim3 grid((unsigned)g), blk(256);
 #define ALGP_LR(DPV)                                                                                              \
-    hipLaunchKernelGGL((lazy_refresh_kernel<T, DPV>), grid, blk, 0, c->cur, M, mode, pos, picks, npicks, ckind, cidx, \
-                       Xs, Cp, n_pool, kernel, os, noise, prevrows, ldv, Vt, dstat, fresh, alive, scores, ss, delta)
+    hipLaunchKernelGGL((lazy_refresh_kernel<T, DPV>), grid, blk, 0, c->cur, M, mode, pos, pos_dev, picks, npicks, ckind, \
+                       cidx, Xs, Cp, n_pool, kernel, os, noise, prevrows, ldv, Vt, dstat, fresh, alive, scores, ss, delta)
     if (DP == 2) ALGP_LR(2);
     else if (DP == 4) ALGP_LR(4);
     else ALGP_LR(8);
@@ -436,10 +443,11 @@ int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const Laz
 }
 template int lazy_refresh_launch<double>(algp_ctx*, int64_t, int, int64_t, const LazyPick*, int, const int*, const int64_t*,
                                          const double*, const double*, int64_t, int, int, double, double, const double*,
-                                         int64_t, double*, double*, int*, const unsigned char*, double*, double, double);
+                                         int64_t, double*, double*, int*, const unsigned char*, double*, double, double,
+                                         const int64_t*);
 template int lazy_refresh_launch<float>(algp_ctx*, int64_t, int, int64_t, const LazyPick*, int, const int*, const int64_t*,
                                         const float*, const float*, int64_t, int, int, float, float, const float*, int64_t,
-                                        float*, float*, int*, const unsigned char*, double*, double, double);
+                                        float*, float*, int*, const unsigned char*, double*, double, double, const int64_t*);
 
 // ---------------------------------------------------------------------------------------------
 // greedy commit bookkeeping on the device (one thread): from the winner's statistic d_c (posterior variance, or

@@ -7,15 +7,18 @@ One "step" = one planning step of the reference's agent at fixed hyper-parameter
              k = 4 greedy picks (arguments.py:22): utilities -> all-gather -> argmax -> rank-1 commit
 Workload (BASELINE.json configs[3] on ONE GPU; it fits: L 0.8 GB + V^T 8.2 GB fp64):
   N = 10 000 train points (100 x 100 mixture-of-Gaussians field, utils.py:90-108), D = 2, fp64,
-  M = 100 000 candidates -- PER GPU with --scaling weak (default: rank r scores its own 100 000),
-  IN TOTAL with --scaling strong (BASELINE config 4: the 100 000 are split over the ranks);
-  information-gain criterion = entropy (the reference's effective default, agent.py:125; the MI criterion
-  needs diag(C_rest^-1) over the whole pool, 2 x 110 000^2 x 8 B = 190 GB of scratch at this size and does not
-  shard: it is timed at a single-GPU size in `extra.mi_criterion`), sigma_s = 0.1, sigma_m = 1.
+  M = 100 000 candidates IN TOTAL (--scaling strong, the headline: BASELINE config 4 -- the 100 000 are split over
+  the ranks, agent.py:317-347 being independent per candidate), or PER GPU with --scaling weak; --scaling both (the
+  default) reports the strong run as the headline and, for N > 1, the weak one under "weak_scaling";
+  information-gain criterion = entropy (the reference's effective default, agent.py:125; the MI criterion needs
+  diag(C_rest^-1) over the whole pool: 2 x 110 000^2 x 8 B = 194 GB of scratch would fit the 288 GB, the two
+  pool-wide O(n^3) factorisations behind it -- 9e14 flop -- are what rules it out at this size; it does not shard
+  and is timed at single-GPU sizes in `extra.mi_criterion`), sigma_s = 0.1, sigma_m = 1.
 Inputs (coordinates, targets, noise) are resident in HBM before the timed region.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
-Prints ONE JSON line on rank 0.
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either under torch.distributed.run, or plainly:
+without WORLD_SIZE in the environment the script starts the N ranks itself as a child `python -m torch.distributed.run`
+(before importing torch or touching HIP) and relays rank 0's line.  Prints ONE JSON line.
 """
 import argparse
 import json
@@ -299,14 +302,50 @@ def extra_mi(_hip, device):
             'candidates_per_s': len(cand) / (ms * 1e-3), 'pick': int(pk[0])}
 
 
+def sources_sha16():
+    """Fingerprint of the kernel sources the PMC traffic figure belongs to (the GEMM and the solve that launches it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('gemm.hip', 'potrf.hip', 'mfma.h'):
+        h.update(open(os.path.join(REPO, 'algp_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` launched plainly: start the N ranks as a CHILD `python -m torch.distributed.run`
+    (never an exec, and before this process has imported torch or touched HIP), relay rank 0's JSON line, exit with the
+    child's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench: no WORLD_SIZE in the environment; starting %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode('utf-8', 'replace').splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    return proc.returncode if proc.returncode != 0 or line is not None else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--train', type=int, default=10000)
-    ap.add_argument('--cand', type=int, default=100000, help='candidates per GPU (weak) or in total (strong)')
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--cand', type=int, default=100000, help='candidates in total (strong) / per GPU (weak)')
+    ap.add_argument('--scaling', default='both', choices=['weak', 'strong', 'both'],
+                    help='strong (BASELINE config 4: the 100 000 candidates are split over the ranks), weak (100 000 per rank), both '
+                         '(default: the headline is the strong run; for N > 1 the weak one follows and is reported under "weak_scaling")')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--picks', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -315,11 +354,15 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo only for rehearsing several ranks on ONE card (RCCL refuses duplicate devices)')
     ap.add_argument('--collective', default='abi', choices=['abi', 'torch'],
-                    help='abi: the all-gather inside the library (algp_greedy_sharded, RCCL); torch: ShardedGreedy over '
-                         'torch.distributed (the cross-check; also what --backend gloo uses)')
+                    help='abi: the all-gather inside the library (algp_greedy_sharded; RCCL with --backend nccl, the caller\'s '
+                         'gloo all-gather handed to algp_comm_init_host with --backend gloo); torch: ShardedGreedy over '
+                         'torch.distributed (the cross-check)')
     ap.add_argument('--cpu-train', type=int, default=6000)
-    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r02_traffic_pmc.json'))
+    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r03_traffic_pmc.json'))
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_spawn(args))
 
     # stdout carries exactly ONE JSON line: libraries that write to fd 1 (RCCL prints a version banner
     # there when the communicator is created) are sent to stderr until the result is printed.
@@ -333,9 +376,7 @@ def main():
     if 'ALGP_BENCH_DEVICE' in os.environ:          # rehearsal: several ranks on one card
         local_rank = int(os.environ['ALGP_BENCH_DEVICE'])
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
-                             % (args.gpus, args.gpus))
+        raise SystemExit('bench: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     import torch
     torch.cuda.set_device(local_rank)
     dist = None
@@ -352,29 +393,29 @@ def main():
     from algp_amd.sharded import LocalComm, ShardedGreedy, TorchComm
 
     dt = np.float64 if args.dtype == 'f64' else np.float32
-    w = build_workload(args, world)
     hyp_vals = dict(ls=[3.0, 3.0], os=1.0, noise=1e-2)
     ctx = _hip.Context(dt, device=local_rank)
     ctx.set_hypers(np.log(hyp_vals['ls']), np.log(hyp_vals['os']), np.log(hyp_vals['noise']))
-    ctx.set_pool(w['pool'])
-    N = w['N']
-    offs = np.concatenate([[0], np.cumsum(w['counts'])])
-    total_c = int(offs[-1])
-    ctx.set_train(np.arange(N), w['y'], w['var'])
-    all_cand = np.arange(N, N + total_c)
-    mine = all_cand[offs[rank]:offs[rank + 1]]
-    ctx.set_candidates(mine, prior_includes_noise=True)
     comm = TorchComm(torch.device('cuda', local_rank)) if dist is not None else LocalComm()
     collective = 'none'
     if dist is not None:
         collective = 'torch.distributed all_gather_into_tensor (%s)' % args.backend
-        if args.collective == 'abi' and args.backend == 'nccl':
-            # the library's own communicator: rank 0 creates the id, torch.distributed only carries the 128 bytes
+        if args.collective == 'abi':
             try:
-                uid = [_hip.Context.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                ctx.comm_init(world, rank, uid[0])
-                collective = 'algp_greedy_sharded: ncclAllGather of (utility, pool index) inside libalgp_hip.so'
+                if args.backend == 'nccl':
+                    # the library's own communicator: rank 0 creates the id, torch.distributed only carries the 128 bytes
+                    uid = [_hip.Context.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(uid, src=0)
+                    ctx.comm_init(world, rank, uid[0])
+                    collective = 'algp_greedy_sharded: ncclAllGather of (utility, pool index, status) inside libalgp_hip.so'
+                else:
+                    def gloo_gather(send):
+                        t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+                        out = torch.empty(world * len(send), dtype=torch.uint8)
+                        dist.all_gather_into_tensor(out, t)
+                        return out.numpy().tobytes()
+                    ctx.comm_init_host(world, rank, gloo_gather)
+                    collective = 'algp_greedy_sharded over algp_comm_init_host (gloo all-gather supplied by the caller)'
             except Exception as e:                                 # keep the run: fall back to the torch collective
                 print('bench: algp_comm_init failed (%s); using the torch.distributed collective' % e, file=sys.stderr)
         flags = [1 if collective.startswith('algp') else 0]
@@ -392,61 +433,115 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    picks_log = []
+    def run_case(scaling):
+        """W warm-up steps, K timed steps with the stage timers, K more without, on the workload of `scaling`."""
+        args.scaling = scaling
+        w = build_workload(args, world)
+        ctx.set_pool(w['pool'])
+        N = w['N']
+        offs = np.concatenate([[0], np.cumsum(w['counts'])])
+        total_c = int(offs[-1])
+        ctx.set_train(np.arange(N), w['y'], w['var'])
+        all_cand = np.arange(N, N + total_c)
+        mine = all_cand[offs[rank]:offs[rank + 1]]
+        ctx.set_candidates(mine, prior_includes_noise=True)
+        picks_log = []
 
-    def step():
-        ctx.fit_and_solve()                                       # = algp_factorize + algp_solve_candidates
-        if dist is None:
-            picks = list(ctx.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks))
-        elif use_abi:
-            picks = list(ctx.greedy_sharded(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks))
-        else:
-            sg = ShardedGreedy(ctx, comm, all_cand)
-            picks, _ = sg.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks)
-        picks_log.append([int(p) for p in picks])
+        def step():
+            ctx.fit_and_solve()                                       # = algp_factorize + algp_solve_candidates
+            if dist is None:
+                picks = list(ctx.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks))
+            elif use_abi:
+                picks = list(ctx.greedy_sharded(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks))
+            else:
+                sg = ShardedGreedy(ctx, comm, all_cand)
+                picks, _ = sg.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks)
+            picks_log.append([int(p) for p in picks])
 
-    def timed(nsteps):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(nsteps):
+        def timed(nsteps):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                step()
+            barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el
+
+        for _ in range(args.warmup):
             step()
-        barrier()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+        # the timed region: K steps with the library's HIP-event profiling on (the roofline figures below come from these
+        # very launches); the same K steps are then repeated without the ~600 event pairs per step
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        s0 = ctx.sync_count()
+        elapsed = timed(args.steps)
+        syncs = ctx.sync_count() - s0
+        prof = {k: ctx.prof_get(k) for k in _hip.PROF}
+        chol_stats = ctx.cholesky_task_stats()
+        ctx.prof_enable(False)
+        elapsed_unprof = timed(args.steps)
+        return dict(w=w, N=N, total_c=total_c, Mloc=int(w['counts'][rank]), M0=int(w['counts'][0]), elapsed=elapsed,
+                    elapsed_unprof=elapsed_unprof, prof=prof, chol_stats=chol_stats, picks=picks_log[-1], step=step,
+                    syncs_per_step=syncs / float(args.steps))
 
-    for _ in range(args.warmup):
-        step()
-    # the timed region: K steps with the library's HIP-event profiling on (the roofline figures below come from these
-    # very launches); the same K steps are then repeated without the ~600 event pairs per step
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    elapsed = timed(args.steps)
-    prof = {k: ctx.prof_get(k) for k in _hip.PROF}
-    chol_stats = ctx.cholesky_task_stats()
-    ctx.prof_enable(False)
-    elapsed_unprof = timed(args.steps)
+    want = args.scaling
+    res = run_case('weak' if want == 'weak' else 'strong')
+    weak = None
+    if want == 'both' and world > 1:
+        weak = run_case('weak')
+        args.scaling = 'strong'
+    elif want == 'both':
+        args.scaling = 'strong'
+
+    serial = None
+    if rank == 0 and world == 1:
+        # the same solve with ONE row-chunk stream: the launches run back to back, so the sum of their own durations is
+        # the GEMM kernel's rate without help from overlapping another stream's tail (what a --pmc pass also measures)
+        try:
+            ctx.set_trsm_chunks(1)
+            res['step']()
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+            for _ in range(2):
+                res['step']()
+            ctx.sync()
+            g1, sp1 = ctx.prof_get('gemm_trsm'), ctx.prof_get('trsm')
+            ctx.prof_enable(False)
+            serial = dict(sum_launch_ms=g1['ms'] / 2, wall_ms=sp1['ms'] / 2, launches=g1['launches'] // 2, flops_executed=g1['flops'] / 2)
+        except Exception as e:
+            print('bench: serial (1 chunk stream) leg failed: %s' % e, file=sys.stderr)
+        finally:
+            ctx.set_trsm_chunks(0)
 
     if rank == 0:
         K = args.steps
+        w, N, total_c, prof, chol_stats = res['w'], res['N'], res['total_c'], res['prof'], res['chol_stats']
+        elapsed, elapsed_unprof = res['elapsed'], res['elapsed_unprof']
         ms_step = 1e3 * elapsed / K
         peak = FP64_MATRIX_PEAK_TFLOPS if args.dtype == 'f64' else FP32_MATRIX_PEAK_TFLOPS
-        es = 8 if args.dtype == 'f64' else 4
-        Mloc = int(w['counts'][0])
+        Mloc = res['Mloc']
         g = prof['gemm_trsm']
         span = prof['trsm']                                       # wall time of the solves (row chunks overlap on 3 streams)
         alg_flops_step = float(N) ** 2 * Mloc                     # SURVEY 8(d): N^2 flop per candidate
         ach = alg_flops_step * K / (span['ms'] * 1e-3) / 1e12 if span['ms'] > 0 else 0.0
         ach_padded = g['flops'] / (span['ms'] * 1e-3) / 1e12 if span['ms'] > 0 else 0.0
-        traffic = None
-        if os.path.exists(args.traffic_json):
-            try:
-                traffic = json.load(open(args.traffic_json)).get('gemm_nt_%s_bytes_per_launch' % args.dtype)
-            except Exception:
-                traffic = None
+        # HBM bytes per launch from the PMC passes (profiles/): only when they were taken on THESE kernel sources
+        traffic, traffic_info = None, {'source': os.path.relpath(args.traffic_json, REPO), 'sources_sha16_now': sources_sha16()}
+        try:
+            tj = json.load(open(args.traffic_json))
+            traffic_info['sources_sha16_measured'] = tj.get('sources_sha16')
+            traffic_info['commit_measured'] = tj.get('commit')
+            if tj.get('sources_sha16') == traffic_info['sources_sha16_now'] and args.train == 10000 and args.cand == 100000 and world == 1:
+                traffic = tj.get('gemm_nt_%s_bytes_per_launch' % args.dtype)
+                traffic_info['bytes_per_solve'] = tj.get('bytes_per_solve_%s' % args.dtype)
+            else:
+                traffic_info['note'] = 'null: the PMC passes were taken on other kernel sources or another workload than this run'
+        except Exception as e:
+            traffic_info['note'] = 'null: %s' % e
         dag = prof['chol_dag']
         fit_ms = prof['cholesky']['ms'] / K                       # wall time of the fit (kernel build, factorisation, z)
         dag_ms = dag['ms'] / K if dag['launches'] else None       # the factorisation proper (one launch)
@@ -465,6 +560,26 @@ def main():
             proj[str(n)] = {'ms_per_step': replicated + sharded_ms / n,
                             'speedup_vs_1': ms_step / (replicated + sharded_ms / n),
                             'scoring_only_speedup_vs_1': float(n)}
+        roof = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<%s> (candidate TRSM)' % ('double' if args.dtype == 'f64' else 'float'),
+                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                'traffic': traffic, 'traffic_provenance': traffic_info,
+                'algorithmic_flops_per_step': alg_flops_step,
+                'algorithmic_flops_per_launch': alg_flops_step * K / max(1, g['launches']),
+                'launches': g['launches'], 'avg_launch_ms': g['ms'] / max(1, g['launches']),
+                'wall_ms_all_launches': span['ms'], 'sum_launch_ms': g['ms'],
+                'achieved_padded': ach_padded, 'padded_flops_per_step': g['flops'] / K,
+                'note': 'achieved = N^2 M flop (SURVEY 8d) / wall time of the solve; the launches of the 3 row chunks '
+                        'overlap on 3 streams, so sum_launch_ms > wall_ms_all_launches and avg_launch_ms (what rocprofv3 '
+                        '--stats reports per launch) is not a denominator by itself; achieved_padded counts the '
+                        'flops actually executed (128-padding + full-square diagonal-block products); serial_kernel_frac is the '
+                        'same algorithmic flop over the SUM of the launches\' own durations when they run back to back on one '
+                        'stream: the kernel\'s rate on these shapes without another stream filling its partial last rounds'}
+        if serial and serial['sum_launch_ms'] > 0:
+            roof['serial_kernel_frac'] = alg_flops_step / (serial['sum_launch_ms'] * 1e-3) / 1e12 / peak
+            roof['serial_kernel_achieved'] = alg_flops_step / (serial['sum_launch_ms'] * 1e-3) / 1e12
+            roof['serial_sum_launch_ms'] = serial['sum_launch_ms']
+            roof['serial_wall_ms'] = serial['wall_ms']
+            roof['serial_avg_launch_ms'] = serial['sum_launch_ms'] / max(1, serial['launches'])
         out = {
             'metric': 'GP-fit+MI-score throughput (N train x M candidates)',
             'value': total_c / (elapsed / K),
@@ -473,27 +588,17 @@ def main():
             'ms_per_step': ms_step,
             'ms_per_step_unprofiled': 1e3 * elapsed_unprof / K,
             'value_unprofiled': total_c / (elapsed_unprof / K),
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'weak' if want == 'weak' else 'strong', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': '%d-point MoG field (train) x %d candidates %s, %d greedy picks, entropy criterion, D=2'
-                                   % (N, args.cand, 'per GPU' if args.scaling == 'weak' else 'in total', args.picks),
+                                   % (N, args.cand, 'per GPU' if want == 'weak' else 'in total (BASELINE config 4: sharded over the ranks)',
+                                      args.picks),
                        'criterion': 'entropy (agent.py:125 default); the MI criterion (agent.py:330-339) needs pool-wide inverse '
-                                    'diagonals -- 190 GB of scratch at this size, not shardable -- and is timed in extra.mi_criterion',
-                       'n_train': N, 'candidates_per_gpu': Mloc, 'candidates_total': total_c,
-                       'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + pool index)' % world,
+                                    'diagonals and does not shard: it is timed in extra.mi_criterion',
+                       'n_train': N, 'candidates_per_gpu': res['M0'], 'candidates_total': total_c,
+                       'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + pool index + status)' % world,
                        'collective': collective},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<%s> (candidate TRSM)' % ('double' if args.dtype == 'f64' else 'float'),
-                         'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                         'traffic': traffic,
-                         'algorithmic_flops_per_step': alg_flops_step,
-                         'algorithmic_flops_per_launch': alg_flops_step * K / max(1, g['launches']),
-                         'launches': g['launches'], 'avg_launch_ms': g['ms'] / max(1, g['launches']),
-                         'wall_ms_all_launches': span['ms'], 'sum_launch_ms': g['ms'],
-                         'achieved_padded': ach_padded, 'padded_flops_per_step': g['flops'] / K,
-                         'note': 'achieved = N^2 M flop (SURVEY 8d) / wall time of the solve; the launches of the 3 row chunks '
-                                 'overlap on 3 streams, so sum_launch_ms > wall_ms_all_launches and avg_launch_ms (what rocprofv3 '
-                                 '--stats reports per launch) is not a denominator by itself; achieved_padded counts the '
-                                 'flops actually executed (128-padding + full-square diagonal-block products)'},
+            'roofline': roof,
             'cholesky': {'fit_ms': fit_ms, 'tflops_n3_over_3_per_fit_ms': chol_tf, 'kernel': 'chol_dag_kernel (one launch)',
                          'kernel_ms': dag_ms,
                          'kernel_tflops': (N ** 3 / 3.0) / (dag_ms * 1e-3) / 1e12 if dag_ms else None,
@@ -506,14 +611,22 @@ def main():
                                                   '(time inside the tasks / 2 workgroups per CU / 256 CUs), in-kernel 100 MHz stamps'}},
             'cholesky_tflops': chol_tf, 'cholesky_ms': fit_ms,
             'stage_ms_per_step': stage,
+            'host_syncs_per_step': res['syncs_per_step'],
             'throughput': {'with_factorisation_candidates_per_s': total_c / (elapsed / K),
                            'scoring_only_candidates_per_s': total_c / (sharded_ms * 1e-3) if sharded_ms > 0 else None,
                            'replicated_fit_ms': replicated, 'sharded_scoring_ms': sharded_ms},
-            'strong_projection': {'note': 'projection from this run\'s stage split, NOT measured: every rank repeats the fit '
-                                          '(replicated_fit_ms), the candidate work divides by the number of ranks',
-                                  'by_gpus': proj},
-            'picks_last_step': picks_log[-1],
+            'picks_last_step': res['picks'],
         }
+        if world == 1:
+            out['strong_projection'] = {'note': 'projection from this run\'s stage split, NOT measured: every rank repeats the fit '
+                                                '(replicated_fit_ms), the candidate work divides by the number of ranks',
+                                        'by_gpus': proj}
+        if weak is not None:
+            out['weak_scaling'] = {'value': weak['total_c'] / (weak['elapsed'] / K), 'unit': 'candidates/s',
+                                   'ms_per_step': 1e3 * weak['elapsed'] / K,
+                                   'ms_per_step_unprofiled': 1e3 * weak['elapsed_unprof'] / K,
+                                   'candidates_per_gpu': weak['M0'], 'candidates_total': weak['total_c'],
+                                   'picks_last_step': weak['picks']}
         extras = {}
         if world == 1 and not args.no_extras:
             ctx.close()

@@ -56,8 +56,8 @@ enum {
     ALGP_PROF_ROWS = 5,        /* row reductions over V^T (variance, mean, updates) */
     ALGP_PROF_SCORE = 6,       /* score + argmax                                    */
     ALGP_PROF_GEMM_OTHER = 7,
-    ALGP_PROF_CHOLESKY = 8,    /* wall time of whole train-set factorisations (two overlapped streams) */
-    ALGP_PROF_TRSM = 9,        /* wall time of whole candidate solves (two overlapped streams)        */
+    ALGP_PROF_CHOLESKY = 8,    /* wall time of whole train-set factorisations (kernel build + factor + z)  */
+    ALGP_PROF_TRSM = 9,        /* wall time of whole candidate solves (row chunks overlap on 3 streams) */
     ALGP_PROF_GEMM_CHOL_UPDATE = 10, /* the Cholesky's K=512 trailing (rank-512) updates, a subset of GEMM_CHOL's work
                                       * counted here instead: the "dense panel update" of the blocked factorisation */
     ALGP_PROF_CHOL_DAG = 11,   /* the Cholesky as one dependency-driven launch (chol_dag.hip): the whole factorisation */
@@ -180,7 +180,8 @@ int algp_posterior_mean(algp_ctx* ctx, const int64_t* idx, int64_t M, void* mu_o
  *   demand (all of them before algp_scores / algp_get_posterior read them).  The index need not be
  *   a local candidate (sharded scoring: every rank commits the global winner).
  * algp_greedy: k picks on one GPU.  utilities_out (k*M doubles, local candidate order) may be
- *   NULL; forced_picks (k pool indices) may be NULL.
+ *   NULL; forced_picks (k pool indices) may be NULL.  With both NULL and the entropy criterion a pick
+ *   is one host round trip (see algp_greedy_sharded: the same chain without the gather).
  * MI criterion (agent.py:330-339) is exact and single-GPU: it needs the pool-wide complement. */
 int algp_scores(algp_ctx* ctx, int criterion, double static_std, double mobile_std, void* out,
                 int out_is_device);
@@ -204,20 +205,39 @@ int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen
 
 /* ---- (e) multi-GPU: the loop over candidates (agent.py:317-347) cut into shards, one process and one ctx per GPU ----
  * Every rank factorises the same train set (algp_factorize) and holds a contiguous slice of the candidate list
- * (algp_set_candidates + algp_solve_candidates).  The only communication of the path is ONE ncclAllGather (RCCL over
- * xGMI) of 16 bytes per rank and pick, issued by the library on the context's stream:
+ * (algp_set_candidates + algp_solve_candidates; a slice may be empty).  The only communication of the path is ONE
+ * all-gather of 24 bytes per rank and pick -- (best local utility, its pool index, status) -- issued by the library on
+ * the context's stream:
  * algp_comm_unique_id: 128 opaque bytes (ncclUniqueId); one rank calls it, the caller hands them to the others.
- * algp_comm_init: joins this ctx to a communicator of `nranks` ranks as `rank` (collective: every rank calls it).
- * algp_greedy_sharded: k picks (entropy criterion; the MI criterion does not shard): per pick the local best
- *   (algp_best_candidate), the all-gather of (utility, pool index), the first maximum in rank order (= np.argmax over
- *   the concatenated scores, agent.py:349, shards being contiguous in rank order), algp_commit_pick of the winner on
- *   every rank.  picks_out: k pool indices (equal on all ranks); utilities_out: their k utilities, or NULL.
- * RCCL is opened with dlopen at algp_comm_init; without it these three return ALGP_ERR_HIP and nothing else is affected. */
+ * algp_comm_init: joins this ctx to an RCCL communicator (xGMI) of `nranks` ranks as `rank` (collective: every rank
+ *   calls it).  RCCL is opened with dlopen here; without it these return ALGP_ERR_HIP and nothing else is affected.
+ * algp_comm_init_host: the same loop over a transport the CALLER owns (MPI, gloo, shared memory): `fn(user, send, recv,
+ *   bytes_per_rank)` must all-gather `bytes_per_rank` bytes of host memory in rank order and return 0; it is called
+ *   once per pick (twice in the rare extra round) by every rank.  This is also how two ranks can share one card.
+ * algp_greedy_sharded: k picks (entropy criterion; the MI criterion does not shard).  Per pick, stream-ordered and with
+ *   a single read-back (40 bytes): each rank's best candidate resolved on the device (argmax, refresh of the rows
+ *   whose bound can still win, argmax), the all-gather, the first maximum in rank order (= np.argmax over the
+ *   concatenated scores, agent.py:349, shards being contiguous in rank order), then the commit of the winner on every
+ *   rank (enqueued, not waited for).  picks_out: k pool indices (equal on all ranks); utilities_out: their k utilities,
+ *   or NULL.  A rank that cannot take part in a pick (no solve, an allocation failure, ...) still joins the gather and
+ *   reports its error code in the status word: EVERY rank then returns that code, nobody commits the pick, nobody hangs. */
+typedef int (*algp_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
 int algp_comm_unique_id(void* out128);
 int algp_comm_init(algp_ctx* ctx, int nranks, int rank, const void* unique_id128);
+int algp_comm_init_host(algp_ctx* ctx, int nranks, int rank, algp_allgather_fn fn, void* user);
 int algp_comm_destroy(algp_ctx* ctx);
 int algp_greedy_sharded(algp_ctx* ctx, int criterion, double static_std, double mobile_std, int k, int64_t* picks_out,
                         double* utilities_out);
+/* Test hooks of the exchange (no reference counterpart).  algp_debug_first_max: the reduction kernel of the gather on a
+ * caller-made buffer of nranks triples (utility, pool index or -1, status) -> out5 = (utility, pool index, owner rank,
+ * status, first rank with a non-zero status).  algp_debug_fail_next_pick: this rank reports `code` (an ALGP_ERR_* >= 2)
+ * instead of a candidate in its next pick.  algp_debug_counter(ctx, 0): stream synchronisations issued so far.
+ * algp_debug_set_trsm_chunks: row-chunk streams of the candidate solve, 1..4 (0: back to the default 3 / $ALGP_TRSM_CHUNKS);
+ * every setting gives the same bits -- bench.py uses 1 to time the GEMM launches back to back. */
+int algp_debug_first_max(algp_ctx* ctx, const double* triples, int nranks, double out5[5]);
+int algp_debug_set_trsm_chunks(algp_ctx* ctx, int chunks);
+int algp_debug_fail_next_pick(algp_ctx* ctx, int code);
+int64_t algp_debug_counter(algp_ctx* ctx, int which);
 
 /* ---- a5 / a8: entropy_from_cov (utils.py:188-194) and set entropies for best_path --------
  * algp_entropy_from_cov: k*CONST + 1/2 log det cov for a host k x k SPD matrix.
@@ -241,10 +261,9 @@ int algp_trsm_right_lt(algp_ctx* ctx, const void* L, int64_t n, const void* B, i
  * returns the number of mismatching outputs (0 expected).                                      */
 int algp_selftest_mfma(algp_ctx* ctx, int* mismatches);
 /* device-resident GEMM timing on pseudo-random operands (no host traffic): average ms per launch
- * of D = C - A B^T (beta_one) or D = -A B^T, m x n x k, lower tiles only or all (`variant` is reserved: the A/B
- * kernels of round 1 are gone, there is one GEMM kernel).                                              */
-int algp_bench_gemm(algp_ctx* ctx, int64_t m, int64_t n, int64_t k, int variant, int lower_only,
-                    int beta_one, int reps, double* ms_per_launch);
+ * of D = C - A B^T (beta_one) or D = -A B^T, m x n x k, lower tiles only or all.                      */
+int algp_bench_gemm(algp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only, int beta_one, int reps,
+                    double* ms_per_launch);
 
 /* ---- resident-buffer access for benchmarks / multi-GPU plumbing --------------------------- */
 int algp_sync(algp_ctx* ctx);

@@ -43,3 +43,49 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(root, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_missing_rccl_is_an_error_return_not_a_crash():
+    """$ALGP_RCCL_PATH names a file that does not exist (and, being set, is the only file tried): the communicator entry
+    points return an error code -- the process stays alive, the library stays usable (dlerror() was called
+    twice and a null char* went into std::string)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from algp_amd import _hip\n"
+            "lib = _hip.load()\n"
+            "import ctypes\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "rc = lib.algp_comm_unique_id(buf)\n"
+            "rc2 = lib.algp_comm_unique_id(buf)\n"
+            "print('RC', rc, rc2, lib.algp_version())\n" % REPO)
+    env = dict(os.environ, ALGP_RCCL_PATH='/nonexistent/librccl_not_here.so')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert 'RC %d %d' % (_hip.ERR_HIP, _hip.ERR_HIP) in r.stdout, r.stdout
+
+
+def test_bench_self_spawn_command_line(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE starts torch.distributed.run as a CHILD with the same arguments and
+    relays exactly one JSON line (no GPU needed: the child is replaced by a stub that prints a line)."""
+    import importlib.util
+    import subprocess
+    import sys
+    import types
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, stdout=None, **kw):
+        seen['cmd'] = cmd
+        return types.SimpleNamespace(returncode=0, stdout=b'noise on stdout\n{"metric": "m", "value": 1.0, "n_gpus": 8}\n')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    rc = bench.self_spawn(types.SimpleNamespace(gpus=8))
+    assert rc == 0
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '8'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '8', '--steps', '2', '--warmup', '1'] and cmd[-7].endswith('bench.py')
