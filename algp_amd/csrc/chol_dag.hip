@@ -21,9 +21,12 @@
 // the critical path); everything older is applied in K = 512 batches (one read + one write of the tile per 512
 // columns keeps the update MFMA-bound instead of HBM-bound).  Each tile receives its updates in ascending k,
 // so the result is bitwise reproducible and independent of the schedule.
-// Hand-off between workgroups (MI355X: per-XCD L2s, per-CU L1s): producer = every wave drains its stores,
-// workgroup barrier, one lane agent-scope release, drain, relaxed agent-scope store of the tile's version;
-// consumer = one wave polls (relaxed agent-scope loads), one agent-scope acquire, drain, barrier, plain loads.
+// Hand-off between workgroups (MI355X: per-XCD L2s that are not coherent with each other, per-CU L1s): producer =
+// every tile element is stored WRITE-THROUGH (sc1: nothing stays dirty in the XCD's L2, so no L2 write-back is needed
+// before the flag -- a release fence writes back every dirty line of the XCD, and with 64 workgroups per XCD writing
+// tiles that was several microseconds per task), every wave drains its stores, workgroup barrier, relaxed agent-scope
+// store of the tile's version; consumer = one wave polls (relaxed agent-scope loads), one agent-scope acquire (this
+// CU's L1), drain, barrier, plain loads.
 #include "common.h"
 #include "mfma.h"
 #include "diag.h"
@@ -186,7 +189,7 @@ __device__ __forceinline__ bool dag_wait(const DagArgs<T>& g, int ticket, const 
 }
 template <typename T>
 __device__ __forceinline__ const int* dag_ver(const DagArgs<T>& g, int i, int j) { return g.ver + (int64_t)i * g.nt + j; }
-// Publish tile (i, j) at version `ver`: all stores drained, barrier, one release, drain, version store.
+// Publish tile (i, j) at version `ver`: every wave's (write-through) stores drained, barrier, version store.
 template <typename T>
 __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, int ver) {
     const int lane = threadIdx.x & 63;
@@ -194,8 +197,10 @@ __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave == 0) {                                           // a wave-uniform branch (see the note at the ticket)
+#if !ALGP_DAG_WT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         if (lane == 0)
             __hip_atomic_store(g.ver + (int64_t)i * g.nt + j, ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -248,11 +253,11 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Cij[gi * g.ld + wc * 64 + j * 16 + fr] = sgn * acc[i][j][r];
+            for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * g.ld + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
         }
 }
 
-// One of `parts` workgroups that share a tile publishes its part: release as in dag_publish, then an agent-scope add
+// One of `parts` workgroups that share a tile publishes its part: drained as in dag_publish, then an agent-scope add
 // to the tile's arrival counter; the workgroup whose add comes last publishes the tile's version for everybody else.
 template <typename T>
 __device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* counter, int parts, int i, int j, int ver) {
@@ -261,8 +266,10 @@ __device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* count
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave == 0) {
+#if !ALGP_DAG_WT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         if (lane == 0) {
             const int before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (before == parts - 1)
@@ -360,7 +367,7 @@ __device__ __forceinline__ void dag_strip_op(const DagArgs<T>& g, char* smem, bo
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) Out[gi * g.ld + wave * 32 + j * 16 + fr] = sgn * acc[i][j][r];
+            for (int j = 0; j < 2; ++j) st_wt(&Out[gi * g.ld + wave * 32 + j * 16 + fr], sgn * acc[i][j][r]);
         }
 }
 

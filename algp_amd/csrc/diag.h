@@ -286,7 +286,7 @@ template <typename T>
 __device__ __forceinline__ void store_block_rowmajor(const T* blk, T* g, int64_t ld, int lane) {
     const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) g[(int64_t)(lg + 4 * q) * ld + li] = blk[(lg + 4 * q) * 17 + li];
+    for (int q = 0; q < 4; ++q) st_wt(&g[(int64_t)(lg + 4 * q) * ld + li], blk[(lg + 4 * q) * 17 + li]);
 }
 // the lower triangle of a diagonal block of L (zeros above the diagonal: the LDS upper part holds the leaf inverse)
 template <typename T>
@@ -296,7 +296,7 @@ __device__ __forceinline__ void store_block_lower(const T* blk, T* g, int64_t ld
     for (int q = 0; q < 4; ++q) {
         const int row = lg + 4 * q;
         const T t = blk[row * 17 + li];
-        g[(int64_t)row * ld + li] = (li <= row) ? t : (T)0;
+        st_wt(&g[(int64_t)row * ld + li], (li <= row) ? t : (T)0);
     }
 }
 // the leaf inverse X_II (transposed upper storage + dinv[]) as a dense lower-triangular block
@@ -309,14 +309,14 @@ __device__ __forceinline__ void store_block_leafinv(const DiagShared<T>& sh, int
     for (int q = 0; q < 4; ++q) {
         const int row = lg + 4 * q;
         const T t = D[li * 17 + row];                          // X[row][li] for li < row
-        g[(int64_t)row * ld + li] = (li < row) ? t : (li == row ? dv : (T)0);
+        st_wt(&g[(int64_t)row * ld + li], (li < row) ? t : (li == row ? dv : (T)0));
     }
 }
 template <typename T>
 __device__ __forceinline__ void store_block_zero(T* g, int64_t ld, int lane) {
     const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) g[(int64_t)(lg + 4 * q) * ld + li] = (T)0;
+    for (int q = 0; q < 4; ++q) st_wt(&g[(int64_t)(lg + 4 * q) * ld + li], (T)0);
 }
 
 // Factor the 128 x 128 block at A (leading dimension lda) in place and write its inverse (dense, 128 x 128, ld 128,

@@ -36,4 +36,20 @@ struct MF<float> {
     static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
+// Write-through store (global_store ... sc1): the bytes leave for memory at once instead of staying dirty in the XCD's
+// L2, so a tile handed to workgroups on other XCDs needs no L2 write-back (buffer_wbl2, which drains EVERY dirty line
+// of the XCD: several microseconds with 64 workgroups writing tiles) before its flag -- only the storing waves' own
+// s_waitcnt vmcnt(0) (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores, drained, then the flag).
+#ifndef ALGP_DAG_WT
+#define ALGP_DAG_WT 1
+#endif
+template <typename T>
+__device__ __forceinline__ void st_wt(T* p, T v) {
+#if ALGP_DAG_WT
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
+
 }  // namespace algp

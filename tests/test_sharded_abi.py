@@ -163,7 +163,7 @@ want, ut = full.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
 want = [int(p) for p in want]
 full.close()
 
-# 1) balanced shards: same picks, bit-equal utilities, winners from both shards (remote commits on both ranks)
+# 1) balanced shards: same picks, same utilities, winners from both shards (remote commits on both ranks)
 lo, hi = partition(len(cand), world)[rank]
 c = make(cand[lo:hi])
 c.comm_init_host(world, rank, gather)
@@ -171,8 +171,8 @@ for rep in range(2):
     c.factorize(); c.solve_candidates()
     got, gut = c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
     assert [int(p) for p in got] == want, (rank, got, want)
-    for p in range(6):
-        assert gut[p] == np.nanmax(ut[p]), (p, gut[p])
+    for p in range(6):          # not bit-equal: a shard of <= 4096 candidates is solved right-looking, the full list left-looking
+        assert abs(gut[p] - np.nanmax(ut[p])) < 1e-11, (p, gut[p], np.nanmax(ut[p]))
 owners = [0 if int(np.where(cand == p)[0][0]) < partition(len(cand), world)[0][1] else 1 for p in want]
 assert len(set(owners)) == 2, owners
 
