@@ -91,6 +91,7 @@ SIGNATURES = {
     'algp_debug_first_max': (C.c_int, [_c_ctx, _dblp, C.c_int, _dblp]),
     'algp_debug_fail_next_pick': (C.c_int, [_c_ctx, C.c_int]),
     'algp_debug_set_trsm_chunks': (C.c_int, [_c_ctx, C.c_int]),
+    'algp_debug_dag_stall': (C.c_int, [_c_ctx, C.c_int]),
     'algp_debug_counter': (C.c_int64, [_c_ctx, C.c_int]),
     'algp_greedy_sharded': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_int, _i64p, _dblp]),
 }
@@ -435,6 +436,10 @@ class Context(object):
 
     def debug_fail_next_pick(self, code):
         self._check(self.lib.algp_debug_fail_next_pick(self.h, int(code)))
+
+    def debug_dag_stall(self, ticket):
+        """The next one-launch factorisation loses the publish of the task with this ticket (spin limit 0.2 s)."""
+        self._check(self.lib.algp_debug_dag_stall(self.h, int(ticket)))
 
     def set_trsm_chunks(self, chunks):
         """Row-chunk streams of the candidate solve (1..4; 0 = default).  Same results for every setting."""

@@ -47,6 +47,7 @@ struct DagCache {          // device copy of one task list of the dependency-dri
     int64_t nt;
     DevBuf tasks;
     int ntasks;
+    int workers;           // workgroups the schedule was simulated for = the grid it is launched with
 };
 
 struct LazyPick {          // device copy of a committed pick for the lazy greedy refresh (vecops.hip)
@@ -111,6 +112,7 @@ struct algp_ctx {
     std::vector<algp::DagCache> dag_cache;   // task lists of the dependency-driven Cholesky, per matrix size
     algp::DevBuf dag_state;              // its per-launch tile versions / control words / per-block log-determinants
     algp::DevBuf dag_stats;              // its in-kernel task accounting (while profiling is on), see algp_cholesky_task_stats
+    algp::DevBuf dag_aux;                // its per-step operands made by the chain team: X_kk^T and W_k^T = L_k+1,k X_kk
     int64_t acc_cols = 0, acc_M = -1;
     int64_t factor_rows_from_vt = 0;     // last factor update: rows of L taken from V^T instead of a triangular solve
     bool alpha_valid = false;            // alpha = L^-T z is computed on first use (scoring does not need it)
@@ -149,6 +151,7 @@ struct algp_ctx {
     int comm_nranks = 1, comm_rank = 0;
     algp::DevBuf commbuf;    // [own triple | gathered triples | winner record]
     int64_t n_syncs = 0;     // stream synchronisations issued by the library (algp_debug_counter)
+    int debug_dag_stall_ticket = -1; // algp_debug_dag_stall: the next one-launch factorisation loses this ticket's publish
     int debug_fail_next_pick = 0;   // algp_debug_fail_next_pick: error code this rank reports in its next pick
 
     // scratch for auxiliary factorizations (entropy_from_cov, set entropies, MI terms, posterior cov)

@@ -233,10 +233,14 @@ int algp_greedy_sharded(algp_ctx* ctx, int criterion, double static_std, double 
  * status, first rank with a non-zero status).  algp_debug_fail_next_pick: this rank reports `code` (an ALGP_ERR_* >= 2)
  * instead of a candidate in its next pick.  algp_debug_counter(ctx, 0): stream synchronisations issued so far.
  * algp_debug_set_trsm_chunks: row-chunk streams of the candidate solve, 1..4 (0: back to the default 3 / $ALGP_TRSM_CHUNKS);
- * every setting gives the same bits -- bench.py uses 1 to time the GEMM launches back to back. */
+ * every setting gives the same bits -- bench.py uses 1 to time the GEMM launches back to back.
+ * algp_debug_dag_stall: in the next one-launch factorisation (chol_dag.hip) the task that draws `ticket` never publishes its
+ * tile and the spin limit drops from 2 s to 0.2 s: its consumers run into the limit, the launch aborts itself and
+ * algp_factorize returns ALGP_ERR_HIP ("stalled") -- the path a lost hand-off would take; the context stays usable. */
 int algp_debug_first_max(algp_ctx* ctx, const double* triples, int nranks, double out5[5]);
 int algp_debug_set_trsm_chunks(algp_ctx* ctx, int chunks);
 int algp_debug_fail_next_pick(algp_ctx* ctx, int code);
+int algp_debug_dag_stall(algp_ctx* ctx, int ticket);
 int64_t algp_debug_counter(algp_ctx* ctx, int which);
 
 /* ---- a5 / a8: entropy_from_cov (utils.py:188-194) and set entropies for best_path --------

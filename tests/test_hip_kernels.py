@@ -213,3 +213,24 @@ def test_set_entropy_and_inverse_diag(ctxs, dt):
     assert relerr(d, np.diag(np.linalg.inv(S))) < tol(dt, 1e-10, 1e-3)
     assert H == pytest.approx(O.entropy_from_cov_chol(S), rel=tol(dt, 1e-11, 1e-4))
     assert c.set_entropy(np.zeros(0, np.int64)) == 0.0
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_cholesky_task_list_stall_is_reported_and_survivable(ctxs, dt):
+    """A hand-off that never happens (test hook: the task with ticket 7 does not publish its tile) must end the one-launch
+    factorisation by its own spin limit (0.2 s under the hook, 2 s otherwise) with ALGP_ERR_HIP "stalled" -- not hang --
+    and the next factorisation in the same context is right again (the launch state is rebuilt per launch)."""
+    import time
+    c = ctxs[np.dtype(dt)]
+    rng = np.random.RandomState(5)
+    n = 1700                                               # 14 tiles of 128: the task list
+    A = spd(n, rng).astype(dt)
+    L0, ld0 = c.cholesky(A)
+    c.debug_dag_stall(7)
+    t0 = time.time()
+    with pytest.raises(_hip.AlgpError) as ei:
+        c.cholesky(A)
+    assert 'stalled' in str(ei.value) and ei.value.code == _hip.ERR_HIP
+    assert time.time() - t0 < 30
+    L1, ld1 = c.cholesky(A)
+    assert np.array_equal(L0, L1) and ld0 == ld1

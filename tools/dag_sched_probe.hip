@@ -1,17 +1,118 @@
-// The host-side list schedule of the one-launch Cholesky (algp_amd/csrc/chol_dag.hip) on its own: critical path of the task
-// graph, simulated makespan, simulated utilisation and chain progress per 500 us.  Needs no GPU.
-// hipcc --offload-arch=gfx950 -O2 -std=c++17 -w -DALGP_DAG_DEBUG tools/dag_sched_probe.hip -o build/dag_sched_probe && build/dag_sched_probe 79
+// The host-side list schedule of the one-launch Cholesky (algp_amd/csrc/chol_dag.hip) on its own.  Needs no GPU.
+//   build/dag_sched_probe 79                 critical path of the task graph, simulated makespan, utilisation and chain
+//                                            progress per 500 us (build with -DALGP_DAG_DEBUG for the report)
+//   build/dag_sched_probe --check LO HI [W]  for every N/128 in [LO, HI] and several worker counts: replay the ticket
+//                                            list IN LIST ORDER on one imaginary bulk worker beside the chain team and check
+//                                            that every task finds its inputs produced by earlier tickets or by the team,
+//                                            that every tile receives its updates exactly once in ascending k, and that the
+//                                            factorisation is complete at the end.  A list that passes cannot deadlock at
+//                                            any residency: the lowest unfinished ticket can always run.
+// hipcc --offload-arch=gfx950 -O2 -std=c++17 -w [-DALGP_DAG_DEBUG] tools/dag_sched_probe.hip -o build/dag_sched_probe
 #include "../algp_amd/csrc/chol_dag.hip"
+#include <string.h>
 namespace algp {
 int fail(algp_ctx*, int code, const std::string&) { return code; }
 void prof_begin(algp_ctx*, int, double, double) {}
 void prof_end(algp_ctx*) {}
 int ensure(algp_ctx*, DevBuf&, size_t) { return 0; }
 }
+using namespace algp;
+
+// what the kernel's waits and publishes do to the tile versions, restated independently of dag_build_schedule's graph
+struct Replay {
+    int nt;
+    std::vector<int> ver, wver;
+    int lead_k = 0, help_k = 0, help_phase = 0;
+    explicit Replay(int n) : nt(n), ver((size_t)n * n, 0), wver(n, 0) {}
+    int& v(int i, int j) { return ver[(size_t)i * nt + j]; }
+    // the chain team advances as far as its inputs allow (leader: diagonal blocks; helpers: strips, in program order)
+    void team() {
+        for (bool moved = true; moved;) {
+            moved = false;
+            if (lead_k < nt && v(lead_k, lead_k) >= lead_k) {
+                if (v(lead_k, lead_k) != lead_k) { printf("diag %d factored at version %d\n", lead_k, v(lead_k, lead_k)); exit(2); }
+                v(lead_k, lead_k) = lead_k + 1;
+                ++lead_k;
+                moved = true;
+            }
+            while (help_k + 1 < nt) {
+                const int k = help_k;
+                bool ok = false;
+                switch (help_phase) {
+                    case 0: ok = v(k, k) >= k + 1 && v(k + 1, k) == k; if (ok) v(k + 1, k) = k + 1; break;           // TRSM(k+1,k)
+                    case 1: ok = v(k + 1, k + 1) == k; if (ok) v(k + 1, k + 1) = k + 1; break;                       // UPD(k+1,k+1,k)
+                    case 2: ok = true; if (k + 3 < nt) wver[k] = 1; break;                                           // W_k
+                    case 3: ok = k + 2 >= nt || v(k + 2, k) == k; if (ok && k + 2 < nt) v(k + 2, k) = k + 1; break;  // TRSM(k+2,k)
+                    case 4: ok = k + 2 >= nt || v(k + 2, k + 1) == k; if (ok && k + 2 < nt) v(k + 2, k + 1) = k + 1; break;
+                    case 5: ok = k + 2 >= nt || v(k + 2, k + 2) == k; if (ok && k + 2 < nt) v(k + 2, k + 2) = k + 1; break;
+                }
+                if (!ok) break;
+                moved = true;
+                if (++help_phase == 6) { help_phase = 0; ++help_k; }
+            }
+        }
+    }
+    bool run(const DagTask& t, int ticket) {
+        const int i = t.i, j = t.j, k0 = t.kk >> 16, k1 = t.kk & 0xffff;
+        auto bad = [&](const char* why) {
+            printf("nt %d ticket %d type %d (%d,%d) k %d..%d: %s\n", nt, ticket, t.type, i, j, k0, k1, why);
+            return false;
+        };
+        if (t.type == DAG_TU) {
+            const int k = j;
+            if (v(i, k) != k) return bad("tile (i,k) is not at version k");
+            if (v(i, k + 1) != k) return bad("tile (i,k+1) is not at version k");
+            if (!wver[k]) return bad("W_k is not there");
+            v(i, k + 1) = k + 1;
+            v(i, k) = k + 1;
+        } else if (t.type == DAG_TRSM) {
+            if (v(i, j) != j) return bad("tile is not at version k");
+            if (v(j, j) < j + 1) return bad("diagonal block not factored");
+            v(i, j) = j + 1;
+        } else if (t.type == DAG_UPD) {
+            if (v(i, j) != k0) return bad("tile is not at version k0");
+            for (int kk = k0; kk < k1; ++kk) {
+                if (v(i, kk) < kk + 1) return bad("L_i,kk not solved");
+                if (v(j, kk) < kk + 1) return bad("L_j,kk not solved");
+            }
+            v(i, j) = k1;
+        } else {
+            return bad("a team task carries a ticket");
+        }
+        return true;
+    }
+};
+
+static bool check(int nt, int W, int workers) {
+    DagSchedule s;
+    dag_build_schedule(nt, W, workers, s);
+    Replay r(nt);
+    r.team();
+    for (size_t t = 0; t < s.tasks.size(); ++t) {
+        if (!r.run(s.tasks[t], (int)t)) return false;
+        r.team();
+    }
+    for (int i = 0; i < nt; ++i)
+        for (int j = 0; j <= i; ++j)
+            if (r.v(i, j) != j + 1) { printf("nt %d workers %d: tile (%d,%d) ends at version %d\n", nt, workers, i, j, r.v(i, j)); return false; }
+    return true;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--check")) {
+        const int lo = argc > 2 ? atoi(argv[2]) : 8, hi = argc > 3 ? atoi(argv[3]) : 192, W = argc > 4 ? atoi(argv[4]) : 4;
+        int n = 0;
+        for (int nt = lo; nt <= hi; ++nt)
+            for (int workers : {512, 64, 2 * DAG_TEAM + 1}) {
+                if (!check(nt, W, workers)) return 1;
+                ++n;
+            }
+        printf("CHECK OK: %d schedules (N/128 = %d..%d, W = %d)\n", n, lo, hi, W);
+        return 0;
+    }
     const int nt = argc > 1 ? atoi(argv[1]) : 79;
-    algp::DagSchedule s;
-    algp::dag_build_schedule(nt, 4, 512, s);
-    printf("nt %d: %zu ticketed tasks\n", nt, s.tasks.size());
+    DagSchedule s;
+    dag_build_schedule(nt, 4, 512, s);
+    printf("nt %d: %zu ticketed tasks, simulated makespan %.0f us\n", nt, s.tasks.size(), s.makespan);
     return 0;
 }
