@@ -9,10 +9,7 @@
 //                       (the first to arrive), with no hand-off in between and its CU to itself
 //     TRSM(i,k)         L_ik = S_ik X_kk^T                                   (MFMA tile product, K = 128)
 //     UPD(i,j,k0,k1)    S_ij -= L_i,[k0,k1) L_j,[k0,k1)^T                    (MFMA tile product, K = 128 (k1-k0))
-//     TU(i,k)           every row's step-to-step recurrence, by one workgroup: S_i,k+1 -= S_ik W_k with the chain's
-//                       W_k = X_kk^T L_k+1,k^T (= L_ik L_k+1,k^T, since L_ik = S_ik X_kk^T), published at once, THEN
-//                       TRSM(i,k).  The next step of the row needs only the first product: one tile product per
-//                       column step on the row's dependency chain instead of two (TRSM, then the update by its result)
+//     TU(i,k)           TRSM(i,k), then UPD(i,k+1,k,k+1) by the same workgroup: every row's step-to-step recurrence
 // executed by persistent workgroups that draw tasks from ONE ordered list with an atomic ticket.  A task waits
 // (bounded spin on per-tile version counters) until its inputs are final; because the list is a topological
 // order and tickets are handed out in list order, every task's producers are already held by running
@@ -44,7 +41,6 @@ enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2, DAG_TU = 3 };
 constexpr int DAG_STRIPS = 4;                                 // row strips of a 128-row tile product on the chain
 constexpr int DAG_TEAM = 1 + DAG_STRIPS;                      // workgroups on the diagonal chain: leader + one helper per strip
 constexpr int DAG_CTRL = 16;                                  // control words
-constexpr int DAG_CNT = 6;                                    // arrival counters per column step (team products)
 struct DagTask {
     int type, i, j, kk;                                        // kk = (k0 << 16) | k1
 };                                                             // DAG_TU: TRSM(i,j) and then UPD(i,j+1,j) by the same workgroup
@@ -54,14 +50,11 @@ struct DagArgs {
     T* L;
     int64_t ld;
     T* invD;
-    T* invT;                                                   // per diagonal block: X_kk^T (upper triangular, dense 128 x 128)
-    T* Wt;                                                     // per column step: W_k^T = L_k+1,k X_kk (128 x 128), see DAG_TU
     const DagTask* tasks;
     int ntasks, nt;
     int* ver;                                                  // nt x nt tile versions (number of column steps applied)
     int* ctrl;                                                 // [0] ticket, [1] abort code, [3] arrival order, [8..8+DAG_TEAM) the team's CUs
-    int* cnt;                                                  // per column step: strips published of the six team products
-    int* wver;                                                 // per column step: 1 once W_k^T is complete
+    int* cnt;                                                  // per column step: strips published of the five team products
     double* ld_blocks;                                         // per diagonal block: sum(log pivots)
     int* info;
     unsigned long long spin_limit;                             // ticks (100 MHz) a wait may spin before it aborts the launch
@@ -215,18 +208,21 @@ __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, i
             __hip_atomic_store(g.ver + (int64_t)i * g.nt + j, ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// One 128 x 128 tile product by the whole workgroup: C <- C - A B^T (sub) or C <- A B^T (A may be C itself: every read
-// of the tile precedes the stores), A and B row-major with k contiguous, nkt k-tiles of 64 bytes.
+// UPD: tile (i, j) -= L_i,[k0,k1) L_j,[k0,k1)^T.  TRSM (upd == false): tile (i, j) <- tile (i, j) X_jj^T, in place.
 template <typename T>
-__device__ __forceinline__ void dag_tile_product(char* smem, bool sub, T* C, int64_t ldc, const T* A0, int64_t lda, const T* B0,
-                                                 int64_t ldb, int nkt) {
+__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     const int lane = threadIdx.x & 63, fr = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
+    T* Cij = g.L + (int64_t)ti * 128 * g.ld + (int64_t)tj * 128;
     acc_t acc[4][4];
-    if (sub) {
+    const T* A0;
+    const T* B0;
+    int64_t ldb;
+    int nkt;
+    if (upd) {
         // acc = -C, then acc += A B^T, then C = -acc
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -234,8 +230,12 @@ __device__ __forceinline__ void dag_tile_product(char* smem, bool sub, T* C, int
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][r] = -C[gi * ldc + wc * 64 + j * 16 + fr];
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = -Cij[gi * g.ld + wc * 64 + j * 16 + fr];
             }
+        A0 = g.L + (int64_t)ti * 128 * g.ld + (int64_t)k0 * 128;
+        B0 = g.L + (int64_t)tj * 128 * g.ld + (int64_t)k0 * 128;
+        ldb = g.ld;
+        nkt = (k1 - k0) * (128 / (4 * F::EPC));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -243,43 +243,27 @@ __device__ __forceinline__ void dag_tile_product(char* smem, bool sub, T* C, int
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+        A0 = Cij;                                              // in place: every read of the tile precedes the stores
+        B0 = g.invD + (int64_t)tj * 128 * 128;
+        ldb = 128;
+        nkt = 128 / (4 * F::EPC);
     }
-    tile_mainloop<T>(smem, A0, lda, B0, ldb, nkt, acc);
-    const T sgn = sub ? (T)-1 : (T)1;
+    tile_mainloop<T>(smem, A0, g.ld, B0, ldb, nkt, acc);
+    const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) st_wt(&C[gi * ldc + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
+            for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * g.ld + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
         }
-}
-template <typename T>
-__device__ __forceinline__ T* dag_tile(const DagArgs<T>& g, int i, int j) { return g.L + (int64_t)i * 128 * g.ld + (int64_t)j * 128; }
-// UPD: tile (i, j) -= L_i,[k0,k1) L_j,[k0,k1)^T
-template <typename T>
-__device__ __forceinline__ void dag_upd(const DagArgs<T>& g, char* smem, int ti, int tj, int k0, int k1) {
-    dag_tile_product<T>(smem, true, dag_tile(g, ti, tj), g.ld, dag_tile(g, ti, k0), g.ld, dag_tile(g, tj, k0), g.ld,
-                        (k1 - k0) * (128 / (4 * MF<T>::EPC)));
-}
-// TRSM: tile (i, k) <- tile (i, k) X_kk^T, in place
-template <typename T>
-__device__ __forceinline__ void dag_trsm(const DagArgs<T>& g, char* smem, int ti, int k) {
-    dag_tile_product<T>(smem, false, dag_tile(g, ti, k), g.ld, dag_tile(g, ti, k), g.ld, g.invD + (int64_t)k * 128 * 128, 128,
-                        128 / (4 * MF<T>::EPC));
-}
-// the row recurrence: tile (i, k+1) -= S_ik W_k, with S_ik the tile BEFORE its TRSM and W_k^T = L_k+1,k X_kk from the chain
-template <typename T>
-__device__ __forceinline__ void dag_row_step(const DagArgs<T>& g, char* smem, int ti, int k) {
-    dag_tile_product<T>(smem, true, dag_tile(g, ti, k + 1), g.ld, dag_tile(g, ti, k), g.ld, g.Wt + (int64_t)k * 128 * 128, 128,
-                        128 / (4 * MF<T>::EPC));
 }
 
 // One of `parts` workgroups that share a tile publishes its part: drained as in dag_publish, then an agent-scope add
 // to the tile's arrival counter; the workgroup whose add comes last publishes the tile's version for everybody else.
 template <typename T>
-__device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* counter, int parts, int* flag, int ver) {
+__device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* counter, int parts, int i, int j, int ver) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -291,7 +275,8 @@ __device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* count
 #endif
         if (lane == 0) {
             const int before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before == parts - 1) __hip_atomic_store(flag, ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == parts - 1)
+                __hip_atomic_store(g.ver + (int64_t)i * g.nt + j, ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -357,15 +342,16 @@ __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t 
         st = (st + 1 == NST) ? 0 : st + 1;
     }
 }
-// a 32-row strip of a tile product by one workgroup: Out <- Out - A B^T (sub) or Out <- A B^T; A: the strip's 32 rows,
-// B: 128 rows, both k-contiguous over 128 columns; Out may be A (every read precedes the stores)
+// strip `part` (rows 32 part .. 32 part + 31) of: UPD  tile (ti, tj) -= L_(ti,k) L_(tj,k)^T
+//                                                TRSM tile (ti, k) <- tile (ti, k) X_kk^T  (in place; tj unused)
 template <typename T>
-__device__ __forceinline__ void dag_strip_product(char* smem, bool sub, T* Out, int64_t ldo, const T* A, int64_t lda, const T* B,
-                                                  int64_t ldb) {
+__device__ __forceinline__ void dag_strip_op(const DagArgs<T>& g, char* smem, bool upd, int part, int ti, int tj, int k) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     const int lane = threadIdx.x & 63, fr = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    T* Lik = g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)k * 128;      // the strip of tile (ti, k)
+    T* Out = upd ? g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)tj * 128 : Lik;
     acc_t acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -373,36 +359,19 @@ __device__ __forceinline__ void dag_strip_product(char* smem, bool sub, T* Out, 
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][r] = sub ? -Out[gi * ldo + wave * 32 + j * 16 + fr] : (T)0;
+            for (int j = 0; j < 2; ++j) acc[i][j][r] = upd ? -Out[gi * g.ld + wave * 32 + j * 16 + fr] : (T)0;
         }
-    strip_mainloop<T>(smem, A, lda, B, ldb, 128 / (4 * F::EPC), acc);
-    const T sgn = sub ? (T)-1 : (T)1;
+    const T* B0 = upd ? g.L + (int64_t)tj * 128 * g.ld + (int64_t)k * 128 : g.invD + (int64_t)k * 128 * 128;
+    strip_mainloop<T>(smem, Lik, g.ld, B0, upd ? g.ld : 128, 128 / (4 * F::EPC), acc);
+    const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) st_wt(&Out[gi * ldo + wave * 32 + j * 16 + fr], sgn * acc[i][j][r]);
+            for (int j = 0; j < 2; ++j) st_wt(&Out[gi * g.ld + wave * 32 + j * 16 + fr], sgn * acc[i][j][r]);
         }
-}
-// strip `part` (rows 32 part .. 32 part + 31) of: UPD  tile (ti, tj) -= L_(ti,k) L_(tj,k)^T
-//                                                TRSM tile (ti, k) <- tile (ti, k) X_kk^T  (in place; tj unused)
-template <typename T>
-__device__ __forceinline__ void dag_strip_op(const DagArgs<T>& g, char* smem, bool upd, int part, int ti, int tj, int k) {
-    T* Lik = g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)k * 128;      // the strip of tile (ti, k)
-    if (upd)
-        dag_strip_product<T>(smem, true, g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)tj * 128, g.ld, Lik, g.ld,
-                             g.L + (int64_t)tj * 128 * g.ld + (int64_t)k * 128, g.ld);
-    else
-        dag_strip_product<T>(smem, false, Lik, g.ld, Lik, g.ld, g.invD + (int64_t)k * 128 * 128, 128);
-}
-// strip `part` of W_k^T = L_(k+1)k X_kk (rows of tile k+1): B = X_kk^T, row-major
-template <typename T>
-__device__ __forceinline__ void dag_strip_w(const DagArgs<T>& g, char* smem, int part, int k) {
-    dag_strip_product<T>(smem, false, g.Wt + (int64_t)k * 128 * 128 + (int64_t)(32 * part) * 128, 128,
-                         g.L + ((int64_t)(k + 1) * 128 + 32 * part) * g.ld + (int64_t)k * 128, g.ld,
-                         g.invT + (int64_t)k * 128 * 128, 128);
 }
 
 template <typename T>
@@ -439,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
                 DAG_CHAINT(k, 0);
                 T* Akk = g.L + (int64_t)k * 128 * g.ld + (int64_t)k * 128;
                 diag128_factor<T>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, g.ld_blocks + k, false, g.info,
-                                  (int64_t)k * 128, g.invT + (int64_t)k * 128 * 128);
+                                  (int64_t)k * 128);
                 DAG_CHAINT(k, 1);
                 dag_publish<T>(g, k, k, k + 1);
                 DAG_CHAINT(k, 2);
@@ -449,14 +418,14 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         const int part = role - 1;
         const bool stamp = role == 1;
         for (int k = 0; k + 1 < nt; ++k) {
-            int* cnt = g.cnt + DAG_CNT * k;
+            int* cnt = g.cnt + 5 * k;
             // L_(k+1)k = S_(k+1)k X_kk^T: needs X_kk and the tile updated k times
             if (!dag_wait<T>(g, -2 - k, lane == 0 ? dag_ver(g, k, k) : (lane == 1 ? dag_ver(g, k + 1, k) : nullptr),
                              lane == 0 ? k + 1 : k, &s_ok)) break;
             if (stamp) DAG_CHAINT(k, 3);
             dag_strip_op<T>(g, sm.gemm, false, part, k + 1, k, k);
             if (stamp) DAG_CHAINT(k, 4);
-            dag_publish_part<T>(g, cnt + 0, DAG_STRIPS, g.ver + (int64_t)(k + 1) * g.nt + k, k + 1);
+            dag_publish_part<T>(g, cnt + 0, DAG_STRIPS, k + 1, k, k + 1);
             if (stamp) DAG_CHAINT(k, 5);
             // S_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T: needs every strip of L_(k+1)k
             if (!dag_wait<T>(g, -2 - k, lane == 0 ? cnt + 0 : (lane == 1 ? dag_ver(g, k + 1, k + 1) : nullptr),
@@ -464,27 +433,22 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
             if (stamp) DAG_CHAINT(k, 6);
             dag_strip_op<T>(g, sm.gemm, true, part, k + 1, k + 1, k);
             if (stamp) DAG_CHAINT(k, 7);
-            dag_publish_part<T>(g, cnt + 1, DAG_STRIPS, g.ver + (int64_t)(k + 1) * g.nt + (k + 1), k + 1);
+            dag_publish_part<T>(g, cnt + 1, DAG_STRIPS, k + 1, k + 1, k + 1);
             if (stamp) DAG_CHAINT(k, 8);
             if (k + 2 >= nt) continue;
-            // W_k^T = L_(k+1)k X_kk for the rows below the team's (DAG_TU): each helper from its own strip of L_(k+1)k
-            if (k + 3 < nt) {
-                dag_strip_w<T>(g, sm.gemm, part, k);
-                dag_publish_part<T>(g, cnt + 5, DAG_STRIPS, g.wver + k, 1);
-            }
             // row k+2, in the shadow of the next diagonal block: L_(k+2)k, then its updates of (k+2,k+1) and (k+2,k+2)
             if (!dag_wait<T>(g, -2 - k, lane == 0 ? dag_ver(g, k + 2, k) : nullptr, k, &s_ok)) break;
             dag_strip_op<T>(g, sm.gemm, false, part, k + 2, k, k);
-            dag_publish_part<T>(g, cnt + 2, DAG_STRIPS, g.ver + (int64_t)(k + 2) * g.nt + k, k + 1);
+            dag_publish_part<T>(g, cnt + 2, DAG_STRIPS, k + 2, k, k + 1);
             if (stamp) DAG_CHAINT(k, 9);
             if (!dag_wait<T>(g, -2 - k, lane == 0 ? cnt + 2 : (lane == 1 ? dag_ver(g, k + 2, k + 1) : nullptr),
                              lane == 0 ? DAG_STRIPS : k, &s_ok)) break;
             dag_strip_op<T>(g, sm.gemm, true, part, k + 2, k + 1, k);
-            dag_publish_part<T>(g, cnt + 3, DAG_STRIPS, g.ver + (int64_t)(k + 2) * g.nt + (k + 1), k + 1);
+            dag_publish_part<T>(g, cnt + 3, DAG_STRIPS, k + 2, k + 1, k + 1);
             if (stamp) DAG_CHAINT(k, 10);
             if (!dag_wait<T>(g, -2 - k, lane == 0 ? dag_ver(g, k + 2, k + 2) : nullptr, k, &s_ok)) break;
             dag_strip_op<T>(g, sm.gemm, true, part, k + 2, k + 2, k);
-            dag_publish_part<T>(g, cnt + 4, DAG_STRIPS, g.ver + (int64_t)(k + 2) * g.nt + (k + 2), k + 1);
+            dag_publish_part<T>(g, cnt + 4, DAG_STRIPS, k + 2, k + 2, k + 1);
             if (stamp) DAG_CHAINT(k, 11);
         }
         return;
@@ -495,7 +459,6 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     unsigned st_steps = 0, st_ntrsm = 0;
     for (;;) {
         if (tid < 64) {
-            // a bulk workgroup that shares its CU with a team or pool member retires
             // a workgroup that shares its CU with a team member retires
             bool beside = lane < DAG_TEAM && __hip_atomic_load(&g.ctrl[8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
             beside = __any(beside);
@@ -514,25 +477,27 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         const int type = task.type, ti = task.i, tj = task.j, k0 = task.kk >> 16, k1 = task.kk & 0xffff;
 
         if (type == DAG_TU) {
-            // every row's recurrence from one column step to the next.  S_i,k+1 -= L_ik L_k+1,k^T with L_ik = S_ik X_kk^T
-            // is S_i,k+1 -= S_ik W_k, W_k = X_kk^T L_k+1,k^T from the chain team: the update does not wait for the row's own
-            // TRSM, so the row's next step (which needs S_i,k+1 only) is ONE tile product away instead of two.  The
-            // TRSM of the tile follows in the same workgroup (it overwrites S_ik, which the update has just read).
+            // every row's recurrence from one column step to the next: L_ik = S_ik X_kk^T, then S_i,k+1 -= L_ik L_k+1,k^T
+            // (TRSM(i,k+1) needs it).  As two tasks the pair cost two tickets and a hand-off through HBM per step and
+            // was the longest path of the whole graph (76 x 78 us for the last row); one workgroup does both, the
+            // second product reading the tile it has just written.
             const int k = tj;
-            if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k) : (lane == 1 ? dag_ver(g, ti, k + 1) : (lane == 2 ? g.wver + k : nullptr)),
-                             lane == 2 ? 1 : k, &s_ok)) break;
+            if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k) : (lane == 1 ? dag_ver(g, k, k) : nullptr),
+                             lane == 0 ? k : k + 1, &s_ok)) break;
             DAG_TRACE(t, 1);
             unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
-            dag_row_step<T>(g, sm.gemm, ti, k);
-            st_upd += __builtin_amdgcn_s_memrealtime() - tick0;
-            ++st_steps;
-            dag_publish<T>(g, ti, k + 1, k + 1);
-            tick0 = __builtin_amdgcn_s_memrealtime();
-            dag_trsm<T>(g, sm.gemm, ti, k);                    // X_kk is there: W_k was made from it
+            dag_tile_op<T>(g, sm.gemm, false, ti, k, k, k + 1);
             st_trsm += __builtin_amdgcn_s_memrealtime() - tick0;
             ++st_ntrsm;
+            if (t != g.skip_publish) dag_publish<T>(g, ti, k, k + 1);
+            if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k + 1) : (lane == 1 ? dag_ver(g, k + 1, k) : nullptr),
+                             lane == 0 ? k : k + 1, &s_ok)) break;
+            tick0 = __builtin_amdgcn_s_memrealtime();
+            dag_tile_op<T>(g, sm.gemm, true, ti, k + 1, k, k + 1);
+            st_upd += __builtin_amdgcn_s_memrealtime() - tick0;
+            ++st_steps;
             DAG_TRACE(t, 2);
-            dag_publish<T>(g, ti, k, k + 1);
+            if (t != g.skip_publish) dag_publish<T>(g, ti, k + 1, k + 1);
             DAG_TRACE(t, 3);
             continue;
         }
@@ -553,8 +518,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         DAG_DBG(1, 2);
         DAG_TRACE(t, 1);
         const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
-        if (type == DAG_UPD) dag_upd<T>(g, sm.gemm, ti, tj, k0, k1);
-        else dag_trsm<T>(g, sm.gemm, ti, tj);
+        dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1);
         const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - tick0;
         if (type == DAG_UPD) { st_upd += ticks; st_steps += (unsigned)(k1 - k0); }
         else { st_trsm += ticks; ++st_ntrsm; }
@@ -603,11 +567,9 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         DagTask t;
         float dur, prio;
         int npred;
-        bool on_chain = false;                                              // the team's work: starts when its inputs are there
-        int cont = -1;                                                      // second half of a ticketed task: starts when this one
-                                                                            // ends, on the same worker
-        bool is_cont = false;
+        bool on_chain = false;
         std::vector<int> succ;
+        std::vector<int> succ_start;                                        // nodes that may start once this one HAS STARTED
     };
     std::vector<Node> nodes;
     std::vector<int> last_writer((size_t)nt * nt, -1), trsm((size_t)nt * nt, -1), diag(nt, -1);
@@ -623,6 +585,13 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     auto edge = [&](int from, int to) {
         if (from < 0) return;
         nodes[from].succ.push_back(to);
+        nodes[to].npred++;
+    };
+    // `to` only needs `from` to have an earlier ticket (it waits for it half-way through, holding its workgroup): in
+    // the simulation it may start as soon as `from` has started
+    auto edge_after_start = [&](int from, int to) {
+        if (from < 0) return;
+        nodes[from].succ_start.push_back(to);
         nodes[to].npred++;
     };
     // durations in microseconds as measured at N = 10 000 (bulk workgroups share a CU's matrix cores in pairs, the
@@ -655,15 +624,9 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             edge(last_writer[(size_t)(k + 1) * nt + (k + 1)], h2);
             last_writer[(size_t)(k + 1) * nt + (k + 1)] = h2;
             prev_h5 = h2;
-            int hw = -1;
-            if (k + 3 < nt) {
-                hw = chain(k + 1, k, D_STRIP);                               // W_k^T = L_(k+1)k X_kk for the rows below the team's
-                edge(h2, hw);
-                prev_h5 = hw;
-            }
             if (k + 2 < nt) {
                 const int h3 = chain(k + 2, k, D_STRIP);                     // TRSM(k+2,k)
-                edge(prev_h5, h3);
+                edge(h2, h3);
                 edge(last_writer[(size_t)(k + 2) * nt + k], h3);
                 trsm[(size_t)(k + 2) * nt + k] = h3;
                 const int h4 = chain(k + 2, k + 1, D_STRIP);                 // UPD(k+2,k+1,k)
@@ -676,22 +639,24 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
                 last_writer[(size_t)(k + 2) * nt + (k + 2)] = h5;
                 prev_h5 = h5;
             }
-            for (int i = k + 3; i < nt; ++i) {
-                // DAG_TU(i,k): the ticketed node is the row step S_i,k+1 -= S_ik W_k (tile (i,k+1) is published when it ends);
-                // the TRSM of tile (i,k) is its continuation on the same worker.  Everything the task waits for it waits
-                // for at its start, and all of that is produced by tasks with earlier tickets or by the team: the
-                // no-deadlock argument of the header holds without further conditions.
-                const int ru = add(DAG_TU, i, k, k, k + 1, D_OP + D_OVH);
-                edge(hw, ru);
-                edge(last_writer[(size_t)i * nt + k], ru);
-                edge(last_writer[(size_t)i * nt + (k + 1)], ru);
-                last_writer[(size_t)i * nt + (k + 1)] = ru;
-                const int tr = add(DAG_CHAIN, i, k, k, k + 1, D_OP + 0.5f * D_OVH);
-                nodes[tr].is_cont = true;
-                nodes[tr].npred = 1;                                         // started by ru's completion, not through edges
-                nodes[ru].cont = tr;
-                trsm[(size_t)i * nt + k] = tr;
-            }
+        }
+        for (int i = k + 3; i < nt; ++i) {
+            // TRSM(i,k) and UPD(i,k+1,k) are one ticketed task (DAG_TU): in the simulation the ticketed node is the first
+            // product (L_ik is published when it ends) and the second a continuation that starts when its other inputs
+            // are there.  The ticket is handed out only after the second product's other input, the tile's last update,
+            // has its ticket (edge_after_start), so that everything a task waits for -- at its start or half-way --
+            // is held by a workgroup that is already running: the no-deadlock argument of the header stays intact.
+            const int tr = add(DAG_TU, i, k, k, k + 1, D_OP + D_OVH);
+            edge(d, tr);
+            edge(last_writer[(size_t)i * nt + k], tr);
+            trsm[(size_t)i * nt + k] = tr;
+            edge_after_start(last_writer[(size_t)i * nt + (k + 1)], tr);
+            const int u = add(DAG_CHAIN, i, k + 1, k, k + 1, D_OP + 0.5f * D_OVH);
+            nodes[u].on_chain = true;
+            edge(tr, u);
+            edge(last_writer[(size_t)i * nt + (k + 1)], u);
+            edge(trsm[(size_t)(k + 1) * nt + k], u);
+            last_writer[(size_t)i * nt + (k + 1)] = u;
         }
         auto upd = [&](int i, int j, int k0, int k1) {
             const int u = add(DAG_UPD, i, j, k0, k1, D_OVH + D_OP * (k1 - k0));
@@ -718,7 +683,6 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     for (int v = n - 1; v >= 0; --v) {
         float b = 0;
         for (int s : nodes[v].succ) b = std::max(b, nodes[s].prio);
-        if (nodes[v].cont >= 0) b = std::max(b, nodes[nodes[v].cont].prio);
         nodes[v].prio = b + nodes[v].dur;
     }
 #ifdef ALGP_DAG_DEBUG
@@ -756,17 +720,28 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     out.tasks.reserve(n);
     float now = 0;
     int freew = workers - 2 * DAG_TEAM, started = 0;                         // the team and its retired CU neighbours
+    std::vector<int> just_started;
     auto release = [&](int v) {                                              // all inputs of v are there
         if (nodes[v].on_chain) {
             DAG_SIM_START(v);
             running.push(PI(now + nodes[v].dur, v));
             ++started;
+            just_started.push_back(v);
         } else {
             ready.push(PI(nodes[v].prio, v));
         }
     };
+    auto drain_started = [&]() {                                             // edge_after_start successors
+        while (!just_started.empty()) {
+            const int v = just_started.back();
+            just_started.pop_back();
+            for (int s2 : nodes[v].succ_start)
+                if (--nodes[s2].npred == 0) release(s2);
+        }
+    };
     for (int v = 0; v < n; ++v)
         if (nodes[v].npred == 0) release(v);
+    drain_started();
     while (started < n) {
         while (freew > 0 && !ready.empty()) {
             const int v = ready.top().second;
@@ -776,22 +751,18 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             DAG_SIM_START(v);
             running.push(PI(now + nodes[v].dur, v));
             --freew;
+            just_started.push_back(v);
+            drain_started();
         }
         if (running.empty()) break;                                          // cannot happen for a DAG
         now = running.top().first;
         while (!running.empty() && running.top().first <= now) {
             const int v = running.top().second;
             running.pop();
-            if (nodes[v].cont >= 0) {                                        // second half of the task: same worker, at once
-                const int cv = nodes[v].cont;
-                DAG_SIM_START(cv);
-                running.push(PI(now + nodes[cv].dur, cv));
-                ++started;
-            } else if (!nodes[v].on_chain) {
-                ++freew;                                                     // a ticketed task (or its second half) has ended
-            }
+            if (!nodes[v].on_chain) ++freew;
             for (int s2 : nodes[v].succ)
                 if (--nodes[s2].npred == 0) release(s2);
+            drain_started();
         }
     }
     out.nt = nt;
@@ -855,7 +826,7 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
     }
     // per-launch state: tile versions, control words, per-block log-determinants (one zeroed block)
     const size_t nver = (size_t)nt * nt;
-    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + (DAG_CNT + 1) * (size_t)nt) + sizeof(double) * nt + 16), 16);
+    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt) + sizeof(double) * nt + 16), 16);
     ALGP_TRY(ensure(c, c->dag_state, state_bytes));
     ALGP_HIP(hipMemsetAsync(c->dag_state.p, 0, state_bytes, c->cur));
     DagArgs<T> g;
@@ -868,18 +839,7 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
     g.ld_blocks = (double*)c->dag_state.p;                     // doubles first (8-byte aligned)
     g.ctrl = (int*)((char*)c->dag_state.p + sizeof(double) * nt);
     g.cnt = g.ctrl + (DAG_CTRL + 3) / 4 * 4;
-    g.wver = g.cnt + DAG_CNT * nt;
-    g.ver = g.wver + nt;
-    // X_kk^T and W_k^T, one 128 x 128 tile each per column step.  The blocks of X_kk^T below its block diagonal are never
-    // written (diag.h) and must read as zeros: cleared when the buffer is (re)allocated
-    {
-        const size_t aux_bytes = 2 * sizeof(T) * (size_t)nt * 128 * 128;
-        const void* before = c->dag_aux.p;
-        ALGP_TRY(ensure(c, c->dag_aux, aux_bytes));
-        if (c->dag_aux.p != before) ALGP_HIP(hipMemsetAsync(c->dag_aux.p, 0, c->dag_aux.cap, c->cur));
-        g.invT = (T*)c->dag_aux.p;
-        g.Wt = g.invT + (size_t)nt * 128 * 128;
-    }
+    g.ver = g.cnt + 5 * nt;
     g.info = info;
     g.spin_limit = 200000000ull;
     g.skip_publish = -1;

@@ -112,7 +112,6 @@ struct algp_ctx {
     std::vector<algp::DagCache> dag_cache;   // task lists of the dependency-driven Cholesky, per matrix size
     algp::DevBuf dag_state;              // its per-launch tile versions / control words / per-block log-determinants
     algp::DevBuf dag_stats;              // its in-kernel task accounting (while profiling is on), see algp_cholesky_task_stats
-    algp::DevBuf dag_aux;                // its per-step operands made by the chain team: X_kk^T and W_k^T = L_k+1,k X_kk
     int64_t acc_cols = 0, acc_M = -1;
     int64_t factor_rows_from_vt = 0;     // last factor update: rows of L taken from V^T instead of a triangular solve
     bool alpha_valid = false;            // alpha = L^-T z is computed on first use (scoring does not need it)

@@ -319,36 +319,15 @@ __device__ __forceinline__ void store_block_zero(T* g, int64_t ld, int lane) {
     for (int q = 0; q < 4; ++q) st_wt(&g[(int64_t)(lg + 4 * q) * ld + li], (T)0);
 }
 
-// block X_IJ of the inverse (LDS, 16 x 17) as block (J, I) of the TRANSPOSED inverse: out[r][c] = X_IJ[c][r]
-template <typename T>
-__device__ __forceinline__ void store_block_transposed(const T* blk, T* g, int64_t ld, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st_wt(&g[(int64_t)(lg + 4 * q) * ld + li], blk[li * 17 + (lg + 4 * q)]);
-}
-// the leaf inverse transposed, X_II^T (upper triangular): out[row][li] = X_II[li][row]
-template <typename T>
-__device__ __forceinline__ void store_block_leafinv_T(const DiagShared<T>& sh, int I, T* g, int64_t ld, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
-    const T* D = sh.S + LBLK(I, I);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = lg + 4 * q;
-        const T t = D[row * 17 + li];                          // X[li][row] for row < li
-        st_wt(&g[(int64_t)row * ld + li], (row < li) ? t : (row == li ? sh.dinv[16 * I + row] : (T)0));
-    }
-}
-
 // Factor the 128 x 128 block at A (leading dimension lda) in place and write its inverse (dense, 128 x 128, ld 128,
-// zeros above the diagonal) to inv_out -- and, when invT_out is given, the inverse TRANSPOSED there (its upper block
-// triangle only: the blocks below the diagonal are never written and must be zero already).  Pipeline per 16-column step p (three barriers):
+// zeros above the diagonal) to inv_out.  Pipeline per 16-column step p (three barriers):
 //   [owners: block column p -> LDS] B1 [wave 0: leaf p | waves 1-3: row p of L -> global, row p-1 of X -> global,
 //   T_pJ = sum_K L_pK X_KJ for the inverse's row p] B2 [all: P_b = A_b X_pp^T; waves 1-3: X_pJ = -X_pp T_pJ] B3
 //   [all: rank-16 update of the register-resident blocks].
 // The inverse is complete one step after the factor: its rows ride in the shadow of the leaves.
 template <typename T>
 __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t lda, T* inv_out, double* logdet_acc,
-                                               bool logdet_atomic, int* info, int64_t block_row0, T* invT_out = nullptr) {
+                                               bool logdet_atomic, int* info, int64_t block_row0) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     const int tid = threadIdx.x;
@@ -402,10 +381,6 @@ __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t 
                     if (J < I) store_block_rowmajor<T>(sh.S + LBLK(I, J), xo + 16 * J, 128, lane);
                     else if (J == I) store_block_leafinv<T>(sh, I, xo + 16 * J, 128, lane);
                     else store_block_zero<T>(xo + 16 * J, 128, lane);
-                    if (invT_out) {
-                        if (J < I) store_block_transposed<T>(sh.S + LBLK(I, J), invT_out + (int64_t)(16 * J) * 128 + 16 * I, 128, lane);
-                        else if (J == I) store_block_leafinv_T<T>(sh, I, invT_out + (int64_t)(16 * I) * 128 + 16 * I, 128, lane);
-                    }
                 }
                 if (w1 == (I % 3))
                     store_block_lower<T>(sh.S + LBLK(I, I), A + (int64_t)(16 * I) * lda + 16 * I, lda, lane);
@@ -466,10 +441,6 @@ __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t 
         for (int J = wave; J < 8; J += 4) {
             if (J < 7) store_block_rowmajor<T>(sh.S + LBLK(7, J), xo + 16 * J, 128, lane);
             else store_block_leafinv<T>(sh, 7, xo + 16 * J, 128, lane);
-            if (invT_out) {
-                if (J < 7) store_block_transposed<T>(sh.S + LBLK(7, J), invT_out + (int64_t)(16 * J) * 128 + 16 * 7, 128, lane);
-                else store_block_leafinv_T<T>(sh, 7, invT_out + (int64_t)(16 * 7) * 128 + 16 * 7, 128, lane);
-            }
         }
         if (wave == 2) store_block_lower<T>(sh.S + LBLK(7, 7), A + (int64_t)(16 * 7) * lda + 16 * 7, lda, lane);
         double v = (tid < 128) ? log((double)sh.dd[tid]) : 0.0;

@@ -21,9 +21,9 @@ using namespace algp;
 // what the kernel's waits and publishes do to the tile versions, restated independently of dag_build_schedule's graph
 struct Replay {
     int nt;
-    std::vector<int> ver, wver;
+    std::vector<int> ver;
     int lead_k = 0, help_k = 0, help_phase = 0;
-    explicit Replay(int n) : nt(n), ver((size_t)n * n, 0), wver(n, 0) {}
+    explicit Replay(int n) : nt(n), ver((size_t)n * n, 0) {}
     int& v(int i, int j) { return ver[(size_t)i * nt + j]; }
     // the chain team advances as far as its inputs allow (leader: diagonal blocks; helpers: strips, in program order)
     void team() {
@@ -41,14 +41,13 @@ struct Replay {
                 switch (help_phase) {
                     case 0: ok = v(k, k) >= k + 1 && v(k + 1, k) == k; if (ok) v(k + 1, k) = k + 1; break;           // TRSM(k+1,k)
                     case 1: ok = v(k + 1, k + 1) == k; if (ok) v(k + 1, k + 1) = k + 1; break;                       // UPD(k+1,k+1,k)
-                    case 2: ok = true; if (k + 3 < nt) wver[k] = 1; break;                                           // W_k
-                    case 3: ok = k + 2 >= nt || v(k + 2, k) == k; if (ok && k + 2 < nt) v(k + 2, k) = k + 1; break;  // TRSM(k+2,k)
-                    case 4: ok = k + 2 >= nt || v(k + 2, k + 1) == k; if (ok && k + 2 < nt) v(k + 2, k + 1) = k + 1; break;
-                    case 5: ok = k + 2 >= nt || v(k + 2, k + 2) == k; if (ok && k + 2 < nt) v(k + 2, k + 2) = k + 1; break;
+                    case 2: ok = k + 2 >= nt || v(k + 2, k) == k; if (ok && k + 2 < nt) v(k + 2, k) = k + 1; break;  // TRSM(k+2,k)
+                    case 3: ok = k + 2 >= nt || v(k + 2, k + 1) == k; if (ok && k + 2 < nt) v(k + 2, k + 1) = k + 1; break;
+                    case 4: ok = k + 2 >= nt || v(k + 2, k + 2) == k; if (ok && k + 2 < nt) v(k + 2, k + 2) = k + 1; break;
                 }
                 if (!ok) break;
                 moved = true;
-                if (++help_phase == 6) { help_phase = 0; ++help_k; }
+                if (++help_phase == 5) { help_phase = 0; ++help_k; }
             }
         }
     }
@@ -59,12 +58,15 @@ struct Replay {
             return false;
         };
         if (t.type == DAG_TU) {
+            // TRSM(i,k), then -- a wait in the middle of the task, the workgroup held -- UPD(i,k+1,k)
             const int k = j;
             if (v(i, k) != k) return bad("tile (i,k) is not at version k");
-            if (v(i, k + 1) != k) return bad("tile (i,k+1) is not at version k");
-            if (!wver[k]) return bad("W_k is not there");
-            v(i, k + 1) = k + 1;
+            if (v(k, k) < k + 1) return bad("diagonal block not factored");
             v(i, k) = k + 1;
+            team();
+            if (v(i, k + 1) != k) return bad("second half: tile (i,k+1) is not at version k (its producer holds a LATER ticket)");
+            if (v(k + 1, k) < k + 1) return bad("second half: L_(k+1)k not solved");
+            v(i, k + 1) = k + 1;
         } else if (t.type == DAG_TRSM) {
             if (v(i, j) != j) return bad("tile is not at version k");
             if (v(j, j) < j + 1) return bad("diagonal block not factored");
