@@ -732,6 +732,7 @@ struct Impl {
         ALGP_TRY(sync(c));
         c->ncols = Npad;
         c->picks.clear();
+        c->mi_valid = false;
         ALGP_TRY(reset_lazy(c));
         c->solved = true;
         c->vt_fact_idx = c->fact_idx;
@@ -946,28 +947,16 @@ struct Impl {
     }
 
     // ------------------------------------------------------------------ greedy
-    // MI criterion extra terms per local candidate: H(A) + H(Abar \ i) - H(all_i)   (agent.py:331-339)
-    static int mi_extra(algp_ctx* c, double ss, double sm, std::vector<double>& extra) {
-        const int64_t n = c->n_pool, M = c->M;
+    // ---- MI criterion (agent.py:330-339): H(A u i) + H(Abar \ i) - H(all_i) per candidate --------------------------------
+    // The last two terms need the diagonals of P = C_AbarAbar^-1 and Q = (C + D_all)^-1 over the WHOLE pool (see
+    // mi_rank1_kernel in vecops.hip).  mi_build factors both matrices once per candidate solve and leaves the triangular
+    // inverses X (P = X X^T) resident; mi_apply_pick folds a committed pick into both diagonals with one pass over each X
+    // (O(n^2)) where the reference -- and round 2 of this library -- refactorised both matrices for every pick.
+    static int mi_build(algp_ctx* c, double ss, double sm) {
+        const int64_t n = c->n_pool;
         if (c->train_has_repeats)
             return fail(c, ALGP_ERR_STATE, "mutual_information: the train set lists a site more than once; fuse its readings first");
-        const double vf = 1.0 / (1.0 / ss + 1.0 / sm), delta = vf - sm;
-        {
-            // The criterion needs diag(C_rest^-1) and diag((C + D)^-1) over the WHOLE pool: two n_pool^2 matrices
-            // (the factor and its triangular inverse).  Say so with the byte count instead of failing half-way
-            // through the allocations -- at the C4 size (110 000 sites, fp64) that is 194 GB.
-            const int64_t npad = round_up(std::max<int64_t>(n, 1), NB);
-            const size_t need = sizeof(T) * (size_t)npad * (size_t)npad * 2 + sizeof(T) * (size_t)npad * NB;
-            const size_t held = c->auxA.cap + c->auxW.cap + c->auxInv.cap;
-            size_t free_b = 0, total_b = 0;
-            ALGP_HIP(hipMemGetInfo(&free_b, &total_b));
-            if (need > held + free_b)
-                return fail(c, ALGP_ERR_OOM,
-                            "mutual_information: the criterion needs the inverse diagonals of two pool-wide matrices: " +
-                                std::to_string(need) + " bytes of scratch for n_pool = " + std::to_string(n) + ", " +
-                                std::to_string(held + free_b) + " available; score this pool with the entropy criterion "
-                                "(it needs the candidates' rows only) or a smaller pool");
-        }
+        const double vf = 1.0 / (1.0 / ss + 1.0 / sm);
         // current state: train set (with its noise) + committed picks
         std::vector<char> sampled(n, 0);
         std::vector<double> noise(n, 0.0);
@@ -981,54 +970,129 @@ struct Impl {
         }
         std::vector<int64_t> A, Abar, all(n);
         std::vector<T> vA, vall(n);
-        std::vector<int64_t> pos_bar(n, -1);
+        c->mi_posbar.assign(n, -1);
         for (int64_t i = 0; i < n; ++i) {
             all[i] = i;
             vall[i] = (T)noise[i];
             if (sampled[i]) { A.push_back(i); vA.push_back((T)noise[i]); }
-            else { pos_bar[i] = (int64_t)Abar.size(); Abar.push_back(i); }
+            else { c->mi_posbar[i] = (int64_t)Abar.size(); Abar.push_back(i); }
+        }
+        const int64_t mb = (int64_t)Abar.size();
+        const int64_t npad = round_up(std::max<int64_t>(n, 1), NB), mbpad = round_up(std::max<int64_t>(mb, 1), NB);
+        {
+            // Three pool-wide matrices are alive at once (one factor being inverted + the two resident inverses): say so
+            // with the byte count instead of failing half-way through the allocations.  At the C4 size (110 000 sites,
+            // fp64) that is 290 GB -- and, more to the point, 2 x n^3/3 = 9e14 flop for the first pick.
+            const size_t need = sizeof(T) * ((size_t)npad * npad * 2 + (size_t)mbpad * mbpad + (size_t)npad * NB +
+                                             (size_t)MAX_APPEND * (npad + mbpad));
+            const size_t held = c->auxA.cap + c->auxInv.cap + c->miXbar.cap + c->miXall.cap + c->miU.cap + c->miW.cap;
+            size_t free_b = 0, total_b = 0;
+            ALGP_HIP(hipMemGetInfo(&free_b, &total_b));
+            if (need > held + free_b)
+                return fail(c, ALGP_ERR_OOM,
+                            "mutual_information: the criterion keeps the triangular inverses of two pool-wide matrices resident: " +
+                                std::to_string(need) + " bytes for n_pool = " + std::to_string(n) + ", " +
+                                std::to_string(held + free_b) + " available; score this pool with the entropy criterion "
+                                "(it needs the candidates' rows only) or a smaller pool");
         }
         double H_A = 0, H_bar = 0, H_all = 0;
-        std::vector<T> inv_bar(std::max<size_t>(Abar.size(), 1)), inv_all(n);
         ALGP_TRY(set_entropy(c, A.data(), (int64_t)A.size(), vA.data(), &H_A));
+        ALGP_TRY(ensure(c, c->miXbar, sizeof(T) * mbpad * mbpad));
+        ALGP_TRY(ensure(c, c->miXall, sizeof(T) * npad * npad));
+        ALGP_TRY(ensure(c, c->miDP, sizeof(T) * mbpad));
+        ALGP_TRY(ensure(c, c->miDQ, sizeof(T) * npad));
+        ALGP_TRY(ensure(c, c->miU, sizeof(T) * (size_t)MAX_APPEND * mbpad));
+        ALGP_TRY(ensure(c, c->miW, sizeof(T) * (size_t)MAX_APPEND * npad));
+        ALGP_TRY(ensure(c, c->miCol, sizeof(T) * npad));
+        ALGP_TRY(ensure(c, c->miPos, sizeof(int64_t) * n));
+        ALGP_TRY(ensure(c, c->miH, sizeof(double) * (3 + 2 * MAX_APPEND)));
         // C_AbarAbar carries no measurement noise (agent.py:331)
-        ALGP_TRY(set_inverse_diag(c, Abar.data(), (int64_t)Abar.size(), nullptr, inv_bar.data(), &H_bar));
-        ALGP_TRY(set_inverse_diag(c, all.data(), n, vall.data(), inv_all.data(), &H_all));
-        extra.assign(M, 0.0);
-        for (int64_t j = 0; j < M; ++j) {
-            const int64_t i = c->cand_idx[j];
-            if (sampled[i]) {
-                extra[j] = H_A + H_bar - (H_all + 0.5 * log1p(delta * (double)inv_all[i]));
-            } else {
-                extra[j] = H_A + (H_bar - ENT_CONST + 0.5 * log((double)inv_bar[pos_bar[i]])) -
-                           (H_all + 0.5 * log1p(ss * (double)inv_all[i]));
-            }
+        if (mb > 0) {
+            int64_t mp;
+            ALGP_TRY(build_set_matrix(c, Abar.data(), mb, nullptr, &mp));
+            double ld = 0;
+            ALGP_TRY(factor_resident(c, p(c->auxA), mb, mbpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
+            H_bar = (double)mb * ENT_CONST + 0.5 * ld;
+            ALGP_TRY(set_identity_launch<T>(c, p(c->miXbar), mbpad, mbpad));
+            ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->miXbar), mbpad, mbpad, p(c->auxA), mbpad, p(c->auxInv)));
+            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXbar), mb, mbpad, mbpad, (const T*)nullptr, p(c->miDP), (T*)nullptr));
         }
+        {
+            int64_t np2;
+            ALGP_TRY(build_set_matrix(c, all.data(), n, vall.data(), &np2));
+            double ld = 0;
+            ALGP_TRY(factor_resident(c, p(c->auxA), n, npad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
+            H_all = (double)n * ENT_CONST + 0.5 * ld;
+            ALGP_TRY(set_identity_launch<T>(c, p(c->miXall), npad, npad));
+            ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->miXall), npad, npad, p(c->auxA), npad, p(c->auxInv)));
+            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXall), n, npad, npad, (const T*)nullptr, p(c->miDQ), (T*)nullptr));
+        }
+        const double Hs[3] = {H_A, H_bar, H_all};
+        ALGP_HIP(hipMemcpyAsync(c->miH.p, Hs, sizeof(Hs), hipMemcpyHostToDevice, c->stream));
+        ALGP_HIP(hipMemcpyAsync(c->miPos.p, c->mi_posbar.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, c->stream));
+        ALGP_TRY(sync(c));                                       // Hs / mi_posbar (a member, but be plain about it) are host memory
+        c->mi_mb = mb;
+        c->mi_mbpad = mbpad;
+        c->mi_npad = npad;
+        c->mi_npicks = (int64_t)c->picks.size();
+        c->mi_base = c->mi_npicks;
+        c->mi_nbar = 0;
+        c->mi_ss = ss;
+        c->mi_sm = sm;
+        c->mi_valid = true;
         return ALGP_OK;
     }
+    // fold pick number q (committed after mi_build) into P, Q and the three entropies: stream-ordered, O(n^2)
+    static int mi_apply_pick(algp_ctx* c, int64_t q, double ss, double sm) {
+        const PickRec& pk = c->picks[(size_t)q];
+        const int r = (int)(q - c->mi_base);                      // its slot in the rank-1 lists
+        const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
+        double* Hs = (double*)c->miH.p;
+        const LazyPick* lp = (const LazyPick*)c->lazypicks.p + q;
+        const int64_t n = c->n_pool, npad = c->mi_npad, mbpad = c->mi_mbpad;
+        if (!pk.in_train) {
+            // the site leaves the complement: column of P = X X^T at its row, then the rank-1 removal
+            const int64_t cb = c->mi_posbar[pk.pool_idx];
+            if (cb < 0) return fail(c, ALGP_ERR_STATE, "mutual_information: a picked site is missing from the complement set");
+            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXbar), c->mi_mb, mbpad, mbpad, p(c->miXbar) + cb * mbpad, (T*)nullptr, p(c->miCol)));
+            ALGP_TRY(mi_rank1_launch<T>(c, c->mi_mb, p(c->miCol), p(c->miU), mbpad, Hs + 3, c->mi_nbar, cb, 0, 0.0, p(c->miDP), Hs + 1,
+                                        (double*)nullptr, lp));
+            c->mi_nbar += 1;
+        }
+        // its noise in C + D_all changes by ss (new site: 0 -> ss) or by v_fused - sm (mobile-sampled site)
+        ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXall), n, npad, npad, p(c->miXall) + pk.pool_idx * npad, (T*)nullptr, p(c->miCol)));
+        ALGP_TRY(mi_rank1_launch<T>(c, n, p(c->miCol), p(c->miW), npad, Hs + 3 + MAX_APPEND, r, pk.pool_idx, 1, pk.in_train ? delta : ss,
+                                    p(c->miDQ), Hs + 2, Hs + 0, lp));
+        return ALGP_OK;
+    }
+    static int mi_scores_enqueue(algp_ctx* c, double ss, double sm, double delta, double* dst) {
+        if (!c->mi_valid || c->mi_ss != ss || c->mi_sm != sm || (int64_t)c->picks.size() < c->mi_npicks) {
+            c->mi_valid = false;
+            ALGP_TRY(mi_build(c, ss, sm));
+        }
+        for (; c->mi_npicks < (int64_t)c->picks.size(); ++c->mi_npicks) ALGP_TRY(mi_apply_pick(c, c->mi_npicks, ss, sm));
+        return mi_score_launch<T>(c, c->M, (const int*)c->ckind.p, (const int64_t*)c->Cidx.p, (const unsigned char*)c->alive.p,
+                                  (const T*)c->dstat.p, ss, delta, (const int64_t*)c->miPos.p, (const T*)c->miDP.p,
+                                  (const T*)c->miDQ.p, (const double*)c->miH.p, dst);
+    }
 
-    // utilities of every row into `dst` (device; null = c->scores), stream-ordered, no synchronisation of its own for the
-    // entropy criterion (the MI terms are assembled through the host)
+    // utilities of every row into `dst` (device; null = c->scores), stream-ordered; the entropy criterion never
+    // synchronises here, the MI criterion only when it (re)builds its pool-wide inverses (first scoring after a solve)
     static int scores_enqueue(algp_ctx* c, int criterion, double static_std, double mobile_std, double* dst) {
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "scores: call algp_solve_candidates first");
         if (!c->prior_noise) return fail(c, ALGP_ERR_STATE, "scores: candidates were set with predictive semantics");
         ALGP_TRY(flush_lazy(c));
         const double ss = static_std * static_std, sm = mobile_std * mobile_std;
         const double delta = 1.0 / (1.0 / ss + 1.0 / sm) - sm;
-        const double* extra_dev = nullptr;
+        if (!dst) dst = (double*)c->scores.p;
         if (criterion == ALGP_CRIT_MUTUAL_INFORMATION) {
-            std::vector<double> extra;
-            ALGP_TRY(mi_extra(c, ss, sm, extra));
-            ALGP_TRY(ensure(c, c->hostStage, sizeof(double) * c->Mpad));
-            ALGP_HIP(hipMemcpyAsync(c->hostStage.p, extra.data(), sizeof(double) * c->M, hipMemcpyHostToDevice, c->stream));
-            ALGP_TRY(sync(c));
-            extra_dev = (const double*)c->hostStage.p;
-        } else if (criterion != ALGP_CRIT_ENTROPY) {
+            ALGP_TRY(mi_scores_enqueue(c, ss, sm, delta, dst));
+        } else if (criterion == ALGP_CRIT_ENTROPY) {
+            ALGP_TRY(score_launch<T>(c, c->M, (const int*)c->ckind.p, (const unsigned char*)c->alive.p, (const T*)c->dstat.p,
+                                     ss, delta, (const double*)nullptr, dst));
+        } else {
             return fail(c, ALGP_ERR_BAD_ARG, "unknown criterion");
         }
-        if (!dst) dst = (double*)c->scores.p;
-        ALGP_TRY(score_launch<T>(c, c->M, (const int*)c->ckind.p, (const unsigned char*)c->alive.p, (const T*)c->dstat.p,
-                                 ss, delta, extra_dev, dst));
         // entropy utilities of up-to-date rows: from here on c->scores can serve as upper bounds (lazy greedy)
         c->bounds_valid = criterion == ALGP_CRIT_ENTROPY;
         c->lazy_ss = ss;
@@ -1467,7 +1531,7 @@ void algp_destroy(algp_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
-                      &c->lrow, &c->remote, &c->commbuf, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->dag_state, &c->dag_stats, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
+                      &c->lrow, &c->remote, &c->commbuf, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->splitk, &c->dag_state, &c->dag_stats, &c->miXbar, &c->miXall, &c->miDP, &c->miDQ, &c->miPos, &c->miU, &c->miW, &c->miCol, &c->miH, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
                       &c->auxVar, &c->auxD, &c->hostStage};
     for (DevBuf* b : bufs) release(c, *b);
     dag_release(c);

@@ -142,6 +142,15 @@ struct algp_ctx {
     bool vt_has_extra = false;
     int64_t kept_cols_last = 0;
 
+    // MI criterion (agent.py:330-339): the triangular inverses of the two pool-wide matrices stay resident between picks
+    // (api.hip mi_build / mi_apply_pick); miH = [H(A), H(Abar), H(all) | signs of the rank-1 terms of P | of Q]
+    algp::DevBuf miXbar, miXall, miDP, miDQ, miPos, miU, miW, miCol, miH;
+    std::vector<int64_t> mi_posbar;      // host: pool index -> row of the complement matrix when it was built (-1: sampled)
+    bool mi_valid = false;
+    int64_t mi_npicks = 0, mi_base = 0, mi_nbar = 0;   // picks folded in; picks.size() at the build; rank-1 terms of P so far
+    int64_t mi_mb = 0, mi_mbpad = 0, mi_npad = 0;
+    double mi_ss = 0, mi_sm = 0;
+
     // multi-GPU: transport of the sharded greedy loop's one all-gather (comm.hip): an RCCL communicator
     // (algp_comm_init), a caller-supplied host all-gather (algp_comm_init_host), or neither (one rank)
     void* comm = nullptr;

@@ -358,6 +358,7 @@ __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t 
             }
         __syncthreads();                                       // B1
         if (p == 0) ALGP_STAMP(2);
+        ALGP_STAMP(8 + 6 * p + 0);
         if (wave == 0) {
             diag_leaf<T>(sh, p, lane);                         // (2)
         } else {
@@ -387,7 +388,9 @@ __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t 
             }
         }
         if (p == 0) ALGP_STAMP(3);
+        ALGP_STAMP(8 + 6 * p + 1);
         __syncthreads();                                       // B2
+        ALGP_STAMP(8 + 6 * p + 2);
         // inverse row p: X_pJ = -X_pp T_pJ overwrites L_pJ (already stored; no later step reads row p of L)
         if (wave > 0) {
 #pragma unroll
@@ -419,8 +422,10 @@ __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t 
 #pragma unroll
             for (int q = 0; q < 4; ++q) Ab[F::row_of(lane, q) * 17 + li] = pacc[q];
         }
+        ALGP_STAMP(8 + 6 * p + 3);
         __syncthreads();                                       // B3
         if (p == 0) ALGP_STAMP(4);
+        ALGP_STAMP(8 + 6 * p + 4);
         // (4) rank-16 update of the register-resident blocks right of the panel: (-C) += P_bi P_bk^T
 #pragma unroll
         for (int u = 0; u < 9; ++u)
@@ -432,6 +437,7 @@ __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t 
                     acc[u] = F::mfma(Pa[li * 17 + 4 * st + lg], Pb[li * 17 + 4 * st + lg], acc[u]);
             }
         if (p == 0) ALGP_STAMP(5);
+        ALGP_STAMP(8 + 6 * p + 5);
     }
     ALGP_STAMP(6);
     __syncthreads();

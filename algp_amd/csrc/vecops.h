@@ -40,6 +40,13 @@ template <typename T>
 int commit_finalize_launch(algp_ctx* c, const T* dsrc, int in_train, double ss, double delta, LazyPick* lp_out,
                            int64_t pool_idx, int64_t ncols, unsigned char* alive_local, double* score_local, double* out2);
 int fresh_at_launch(algp_ctx* c, const int* fresh, const int64_t* idx, double* out);
+// MI criterion: fold one committed pick into a resident inverse (its diagonal, its rank-1 list, its entropy), and score
+template <typename T>
+int mi_rank1_launch(algp_ctx* c, int64_t m, const T* col0, T* U, int64_t ldu, double* sgn, int q, int64_t cpos, int mode,
+                    double dlt, T* diag, double* H, double* H_A, const LazyPick* pick);
+template <typename T>
+int mi_score_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const unsigned char* alive, const T* dstat,
+                    double ss, double delta, const int64_t* posbar, const T* dP, const T* dQ, const double* Hs, double* out);
 template <typename T>
 int kgemv_launch(algp_ctx* c, int64_t M, const int64_t* qidx, const T* Xs, int DP, int64_t N, const int64_t* aidx,
                  const T* alpha, int kernel, T os, T ybar, T* mu);

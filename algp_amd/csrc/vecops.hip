@@ -486,6 +486,99 @@ template int commit_finalize_launch<double>(algp_ctx*, const double*, int, doubl
 template int commit_finalize_launch<float>(algp_ctx*, const float*, int, double, double, LazyPick*, int64_t, int64_t,
                                            unsigned char*, double*, double*);
 
+// ---------------------------------------------------------------------------------------------
+// MI criterion (agent.py:330-339).  Besides the entropy gain, the utility of candidate i needs H(Abar \ i) and H(all_i):
+//   H(Abar \ i) = H(Abar) - CONST + 1/2 log [C_AbarAbar^-1]_ii                 (i not sampled)
+//   H(all_i)    = H(all)  + 1/2 log(1 + d_i [(C + D_all)^-1]_ii),  d_i = ss (new site) | v_fused - sm (mobile-sampled)
+// i.e. the DIAGONALS of two pool-wide inverses, P = C_AbarAbar^-1 and Q = (C + D_all)^-1.  Both are kept as their
+// triangular factors' inverses X (P = X X^T), computed once per candidate solve; a committed pick c is a rank-1 change
+//   removal of site c from Abar:   P <- P - p p^T / P_cc,                 p = P[:, c]
+//   noise change d at site c:      Q <- Q - g q q^T,  g = d/(1 + d Q_cc),  q = Q[:, c]
+// so each pick costs one pass over X (column c of X X^T = X times row c of X, rows_reduce_kernel) plus this kernel,
+// which removes the earlier picks' rank-1 terms from that column, appends the new term u (sign sg) to the list and
+// updates the diagonal and the entropy: O(n^2) per pick instead of two O(n^3) factorisations.
+//   mode 0 (removal): u = p / sqrt(P_cc), sg = +1, H += -CONST + 1/2 log P_cc
+//   mode 1 (noise):   u = q sqrt|g|,      sg = sign g, H += 1/2 log(1 + d Q_cc); also H_A += the pick's own entropy gain,
+//                     read off the scale of its appended row (LazyPick): new site CONST - log scale, mobile-sampled
+//                     1/2 log(-d) - log scale
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mi_rank1_kernel(int64_t m, const T* col0, T* U, int64_t ldu, double* sgn, int q, int64_t cpos,
+                                                       int mode, double dlt, T* diag, double* H, double* H_A, const LazyPick* pick) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double pc = (double)col0[cpos];
+    for (int r = 0; r < q; ++r) {
+        const double uc = (double)U[(int64_t)r * ldu + cpos];
+        pc -= sgn[r] * uc * uc;
+    }
+    double fac, sg;
+    if (mode == 0) { fac = 1.0 / sqrt(pc); sg = 1.0; }
+    else {
+        const double g = dlt / (1.0 + dlt * pc);
+        fac = sqrt(fabs(g));
+        sg = g >= 0.0 ? 1.0 : -1.0;
+    }
+    if (j < m) {
+        double cj = (double)col0[j];
+        for (int r = 0; r < q; ++r) cj -= sgn[r] * (double)U[(int64_t)r * ldu + j] * (double)U[(int64_t)r * ldu + cpos];
+        const double u = cj * fac;
+        U[(int64_t)q * ldu + j] = (T)u;
+        diag[j] = (T)((double)diag[j] - sg * u * u);
+    }
+    if (j == 0) {
+        // every thread read sgn[0..q) and H before this block's thread 0 writes slot q / H: other blocks may still be
+        // reading sgn[r < q] (untouched here); slot q and H are written once per launch
+        sgn[q] = sg;
+        *H += mode == 0 ? -ENT_CONST + 0.5 * log(pc) : 0.5 * log1p(dlt * pc);
+        if (H_A) *H_A += (pick->in_train ? 0.5 * log(-dlt) : ENT_CONST) - log(pick->scale);
+    }
+}
+template <typename T>
+int mi_rank1_launch(algp_ctx* c, int64_t m, const T* col0, T* U, int64_t ldu, double* sgn, int q, int64_t cpos, int mode,
+                    double dlt, T* diag, double* H, double* H_A, const LazyPick* pick) {
+    hipLaunchKernelGGL(mi_rank1_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->cur, m, col0, U, ldu, sgn, q, cpos,
+                       mode, dlt, diag, H, H_A, pick);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int mi_rank1_launch<double>(algp_ctx*, int64_t, const double*, double*, int64_t, double*, int, int64_t, int, double, double*,
+                                     double*, double*, const LazyPick*);
+template int mi_rank1_launch<float>(algp_ctx*, int64_t, const float*, float*, int64_t, double*, int, int64_t, int, double, float*,
+                                    double*, double*, const LazyPick*);
+
+// MI utility of every candidate from the device-resident terms: entropy gain + H(A) + H(Abar \ i) - H(all_i)
+// Hs = (H(A), H(Abar), H(all)); posbar: pool index -> row of the complement matrix
+template <typename T>
+__global__ void mi_score_kernel(int64_t M, const int* ckind, const int64_t* cidx, const unsigned char* alive, const T* dstat,
+                                double ss, double delta, const int64_t* posbar, const T* dP, const T* dQ, const double* Hs,
+                                double* out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double u = -INFINITY;
+    if (alive[j]) {
+        const bool unit = ckind[j] >= 0;
+        const int64_t pj = cidx[j];
+        u = entropy_utility((double)dstat[j], unit, ss, delta) + Hs[0];
+        if (unit) u += Hs[1] - (Hs[2] + 0.5 * log1p(delta * (double)dQ[pj]));
+        else u += (Hs[1] - ENT_CONST + 0.5 * log((double)dP[posbar[pj]])) - (Hs[2] + 0.5 * log1p(ss * (double)dQ[pj]));
+    }
+    out[j] = u;
+}
+template <typename T>
+int mi_score_launch(algp_ctx* c, int64_t M, const int* ckind, const int64_t* cidx, const unsigned char* alive, const T* dstat,
+                    double ss, double delta, const int64_t* posbar, const T* dP, const T* dQ, const double* Hs, double* out) {
+    if (M <= 0) return ALGP_OK;
+    ProfScope ps(c, ALGP_PROF_SCORE, 12.0 * M, (3.0 * sizeof(T) + 21.0) * M);
+    hipLaunchKernelGGL(mi_score_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->cur, M, ckind, cidx, alive, dstat,
+                       ss, delta, posbar, dP, dQ, Hs, out);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int mi_score_launch<double>(algp_ctx*, int64_t, const int*, const int64_t*, const unsigned char*, const double*, double,
+                                     double, const int64_t*, const double*, const double*, const double*, double*);
+template int mi_score_launch<float>(algp_ctx*, int64_t, const int*, const int64_t*, const unsigned char*, const float*, double,
+                                    double, const int64_t*, const float*, const float*, const double*, double*);
+
 // out[0] = fresh[*idx] (as a double; -1 when *idx < 0): rides with the argmax read-back of the lazy greedy
 __global__ void fresh_at_kernel(const int* fresh, const int64_t* idx, double* out) {
     const int64_t i = *idx;

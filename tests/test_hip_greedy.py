@@ -299,6 +299,55 @@ def test_mi_criterion_at_5000_sites_matches_oracle():
     c.close()
 
 
+@pytest.mark.parametrize('dtname', ['f64', 'f32'])
+def test_mi_criterion_rank1_updates_follow_the_oracle_pick_by_pick(dtname):
+    """Picks 2..k of the MI criterion fold the previous winner into the two resident inverse diagonals (O(n^2) rank-1
+    updates, api.hip mi_apply_pick) where the reference and the oracle refactorise two pool-wide matrices per pick
+    (agent.py:330-339): every utility of 6 forced picks against the oracle's from-scratch terms -- new sites AND
+    mobile-sampled sites among the picks (the latter change the noise of a site that stays outside the complement)."""
+    dt = np.float64 if dtname == 'f64' else np.float32
+    rng = np.random.RandomState(21)
+    grid, _ = O.generate_gaussian_data(40, 50, k=5, rng=rng)
+    X = grid.astype(np.float64)
+    n = len(X)
+    hyp = O.Hypers(np.log([1.5, 1.5]), 0.0, np.log(1e-2))
+    perm = rng.permutation(n)
+    static = np.zeros(n, bool)
+    mobile = np.zeros(n, bool)
+    static[perm[:300]] = True
+    mobile[perm[250:600]] = True
+    A = np.where(static | mobile)[0]
+    var = np.where(static[A] & mobile[A], 1.0 / (1.0 / 0.01 + 1.0), np.where(static[A], 0.01, 1.0))
+    Cm = O.kernel_matrix(hyp, X) + hyp.noise * np.eye(n)
+    cand = np.where(~static)[0]
+    mob_only = np.where(mobile & ~static)[0]
+    free, _ = O.greedy_fast(Cm, static, mobile, 0.1, 1.0, 2, 'mutual_information')
+    forced = [free[0], int(mob_only[3]), free[1], int(mob_only[77]), int(cand[5]), int(mob_only[100])]
+    assert len(set(forced)) == 6
+    picks, ut = O.greedy_fast(Cm, static, mobile, 0.1, 1.0, 6, 'mutual_information', forced_picks=forced)
+    c = _hip.Context(dt)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise)
+    c.set_pool(X)
+    c.set_train(A, np.zeros(len(A)), var)
+    c.factorize()
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    got, gut = c.greedy(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0, 6, forced_picks=forced, want_utilities=True)
+    assert [int(p) for p in got] == forced
+    rel = 1e-7 if dtname == 'f64' else 3e-3
+    for k in range(6):
+        want = ut[k][cand]
+        live = np.isfinite(want)
+        assert np.array_equal(np.isfinite(gut[k]), live), k
+        scale = np.max(np.abs(want[live]))
+        assert np.max(np.abs(gut[k][live] - want[live])) <= rel * scale, (k, np.max(np.abs(gut[k][live] - want[live])), scale)
+    # a second run in the same context rebuilds the inverses after the solve and gives the same bits
+    c.solve_candidates()
+    got2, gut2 = c.greedy(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0, 6, forced_picks=forced, want_utilities=True)
+    assert np.array_equal(gut2, gut)
+    c.close()
+
+
 def test_mi_criterion_reports_the_scratch_it_needs():
     """At a pool the two pool-wide scratch matrices cannot fit (2 x 200 000^2 x 8 B = 640 GB) the MI criterion must
     fail up front with ALGP_ERR_OOM and the byte count, leaving the context usable."""
@@ -316,7 +365,7 @@ def test_mi_criterion_reports_the_scratch_it_needs():
     c.solve_candidates()
     with pytest.raises(MemoryError) as ei:                          # ALGP_ERR_OOM
         c.scores(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0)
-    assert 'bytes of scratch' in str(ei.value) and str(n) in str(ei.value)
+    assert 'bytes for n_pool' in str(ei.value) and str(n) in str(ei.value)
     s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)                      # the entropy criterion still works
     assert np.all(np.isfinite(s))
     c.close()
