@@ -15,7 +15,7 @@ import numpy as np
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libalgp_hip.so')
+LIB_PATH = os.environ.get('ALGP_LIB') or os.path.join(_HERE, 'lib', 'libalgp_hip.so')   # $ALGP_LIB: another build, for A/B timing
 
 F32, F64 = 0, 1
 KERNEL_RBF, KERNEL_MATERN15 = 0, 1

@@ -55,7 +55,7 @@ struct DagArgs {
     int* ver;                                                  // nt x nt tile versions (number of column steps applied)
     int* ctrl;                                                 // [0] ticket, [1] abort code, [3] arrival order, [8..8+DAG_TEAM) the team's CUs
     int* cnt;                                                  // per column step: strips published of the five team products
-    double* ld_blocks;                                         // per diagonal block: sum(log pivots)
+    double* pivots;                                            // the nt * 128 pivots d_j (their logarithms are summed by dag_finish_kernel)
     int* info;
     unsigned long long spin_limit;                             // ticks (100 MHz) a wait may spin before it aborts the launch
     int skip_publish;                                          // test hook: the bulk task with this ticket never publishes (-1: none)
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
                 if (!dag_wait<T>(g, -2 - k, lane == 0 ? dag_ver(g, k, k) : nullptr, k, &s_ok)) break;
                 DAG_CHAINT(k, 0);
                 T* Akk = g.L + (int64_t)k * 128 * g.ld + (int64_t)k * 128;
-                diag128_factor<T>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, g.ld_blocks + k, false, g.info,
-                                  (int64_t)k * 128);
+                diag128_factor<T, true>(sm.diag, Akk, g.ld, g.invD + (int64_t)k * 128 * 128, nullptr, false, g.info,
+                                        (int64_t)k * 128, g.pivots + (int64_t)k * 128);
                 DAG_CHAINT(k, 1);
                 dag_publish<T>(g, k, k, k + 1);
                 DAG_CHAINT(k, 2);
@@ -537,12 +537,18 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     DAG_DBG(1, 5);
 }
 
-// sum of the per-block log-determinants in block order (deterministic), abort code -> info
-__global__ void dag_finish_kernel(const double* ld_blocks, int nt, const int* ctrl, double* logdet_acc, int* info) {
+// log det = sum of the logarithms of the n pivots, in a fixed order (thread t takes pivots t, t + 256, ...; the 256 partial
+// sums are added in thread order): the same bits in every run.  Abort code -> info.
+__global__ __launch_bounds__(256) void dag_finish_kernel(const double* pivots, int n, const int* ctrl, double* logdet_acc, int* info) {
+    __shared__ double part[256];
+    double s = 0;
+    for (int j = threadIdx.x; j < n; j += 256) s += log(pivots[j]);
+    part[threadIdx.x] = s;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double s = 0;
-        for (int k = 0; k < nt; ++k) s += ld_blocks[k];
-        *logdet_acc += s;
+        double tot = 0;
+        for (int t = 0; t < 256; ++t) tot += part[t];
+        *logdet_acc += tot;
         if (ctrl[1] != 0) *info = -2147483647 - 1;             // stalled: reported as a HIP-level failure by the caller
     }
 }
@@ -826,7 +832,7 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
     }
     // per-launch state: tile versions, control words, per-block log-determinants (one zeroed block)
     const size_t nver = (size_t)nt * nt;
-    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt) + sizeof(double) * nt + 16), 16);
+    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt) + sizeof(double) * 128 * nt + 16), 16);
     ALGP_TRY(ensure(c, c->dag_state, state_bytes));
     ALGP_HIP(hipMemsetAsync(c->dag_state.p, 0, state_bytes, c->cur));
     DagArgs<T> g;
@@ -836,8 +842,8 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
     g.tasks = (const DagTask*)dc->tasks.p;
     g.ntasks = dc->ntasks;
     g.nt = nt;
-    g.ld_blocks = (double*)c->dag_state.p;                     // doubles first (8-byte aligned)
-    g.ctrl = (int*)((char*)c->dag_state.p + sizeof(double) * nt);
+    g.pivots = (double*)c->dag_state.p;                        // doubles first (8-byte aligned)
+    g.ctrl = (int*)((char*)c->dag_state.p + sizeof(double) * 128 * nt);
     g.cnt = g.ctrl + (DAG_CTRL + 3) / 4 * 4;
     g.ver = g.cnt + 5 * nt;
     g.info = info;
@@ -864,7 +870,7 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
         hipLaunchKernelGGL(chol_dag_kernel<T>, dim3(grid), dim3(256), 0, c->cur, g);
         ALGP_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(dag_finish_kernel, dim3(1), dim3(64), 0, c->cur, g.ld_blocks, nt, g.ctrl, logdet_acc, info);
+    hipLaunchKernelGGL(dag_finish_kernel, dim3(1), dim3(256), 0, c->cur, g.pivots, 128 * nt, g.ctrl, logdet_acc, info);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

@@ -82,6 +82,17 @@ __device__ __forceinline__ float lane_bcast(float x, int src) {
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// Per-lane choice between an LDS value t, the diagonal entry dv and zero, as in (k < i ? t : k == i ? dv : 0), written as
+// t * m1 + dv * m2 with 0/1 masks: given the select, the compiler sinks the LDS read into a divergent branch (an
+// exec-masked ds_read per case with a waitcnt each: 180 such branches in this kernel) instead of reading unconditionally.
+// (The masked-out values are finite -- other entries of the same factor -- unless the block is not positive definite,
+// which the leaves report anyway.)
+template <typename T>
+__device__ __forceinline__ T pick3(T t, bool use_t, T dv, bool use_d) {
+    return fma_t(t, use_t ? (T)1 : (T)0, dv * (use_d ? (T)1 : (T)0));
+}
+
+
 // Diagnostic builds only (tools/diag_test.hip): cycle stamps of thread 0 at phase boundaries.
 #ifdef ALGP_POTRF_STAMPS
 __device__ unsigned long long g_potrf_stamps[64];
@@ -281,178 +292,350 @@ __device__ __forceinline__ void inv_store(DiagShared<T>& sh, int r0, int J, cons
 }
 
 // ---- 16 x 16 block movers between the LDS image and global memory (one wave; 128-byte row segments in fp64) ----
-// lane (column li, group lg) moves rows lg + 4q
+// lane (column li, group lg) moves rows lg + 4q.  Addresses are a wave-uniform base (block start + 4 q rows: scalar
+// arithmetic) plus ONE 32-bit per-lane offset (lg * ld + li): a 128-row tile spans far less than 4 GB.  Written as
+// row * ld per access, the compiler kept a 64-bit product per row alive across the whole panel loop (32 rows: 64
+// registers, spilled in the one-launch kernel).
 template <typename T>
 __device__ __forceinline__ void store_block_rowmajor(const T* blk, T* g, int64_t ld, int lane) {
     const int li = lane & 15, lg = lane >> 4;
+    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st_wt(&g[(int64_t)(lg + 4 * q) * ld + li], blk[(lg + 4 * q) * 17 + li]);
+    for (int q = 0; q < 4; ++q) st_wt(g + (int64_t)(4 * q) * ld + vo, blk[(lg + 4 * q) * 17 + li]);
 }
 // the lower triangle of a diagonal block of L (zeros above the diagonal: the LDS upper part holds the leaf inverse)
 template <typename T>
 __device__ __forceinline__ void store_block_lower(const T* blk, T* g, int64_t ld, int lane) {
     const int li = lane & 15, lg = lane >> 4;
+    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = lg + 4 * q;
         const T t = blk[row * 17 + li];
-        st_wt(&g[(int64_t)row * ld + li], (li <= row) ? t : (T)0);
+        st_wt(g + (int64_t)(4 * q) * ld + vo, (li <= row) ? t : (T)0);
     }
 }
 // the leaf inverse X_II (transposed upper storage + dinv[]) as a dense lower-triangular block
 template <typename T>
 __device__ __forceinline__ void store_block_leafinv(const DiagShared<T>& sh, int I, T* g, int64_t ld, int lane) {
     const int li = lane & 15, lg = lane >> 4;
+    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
     const T* D = sh.S + LBLK(I, I);
     const T dv = sh.dinv[16 * I + li];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = lg + 4 * q;
         const T t = D[li * 17 + row];                          // X[row][li] for li < row
-        st_wt(&g[(int64_t)row * ld + li], (li < row) ? t : (li == row ? dv : (T)0));
+        st_wt(g + (int64_t)(4 * q) * ld + vo, (li < row) ? t : (li == row ? dv : (T)0));
     }
 }
 template <typename T>
 __device__ __forceinline__ void store_block_zero(T* g, int64_t ld, int lane) {
     const int li = lane & 15, lg = lane >> 4;
+    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st_wt(&g[(int64_t)(lg + 4 * q) * ld + li], (T)0);
+    for (int q = 0; q < 4; ++q) st_wt(g + (int64_t)(4 * q) * ld + vo, (T)0);
+}
+
+// LDS traffic complete, then the workgroup barrier.  (Not __syncthreads(): that also drains vmcnt, and the bulk waves keep
+// write-through stores of finished rows in flight across these barriers.)
+__device__ __forceinline__ void diag_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- operand fragments of the 16 x 16 x 16 block products below.  One product is four MFMAs (k = 16 in steps of 4); the
+// k index a lane feeds in step st is kperm(lg, st) = 4 lg + st for BOTH operands, so that a lane's four A values are
+// contiguous in a row of the LDS image (two ds_read2 instead of four reads) -- any bijection of k works as long as A and
+// B agree.  Reads are gathered for several independent products first, then their MFMAs are issued interleaved, then
+// the results are written: a product chain is four dependent MFMAs (~32 cycles each) behind an LDS round trip, and
+// the compiler cannot hoist the next product's LDS reads over the previous product's LDS writes (may alias).
+template <typename T>
+struct Frag { T v[4]; };
+// A[i = li][k] of a row-major 16 x 17 block
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_rows(const T* blk, int li, int lg, bool on) {
+    Frag<T> f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) f.v[st] = blk[li * 17 + 4 * lg + st];
+    if (!on) {                                                 // wave-uniform
+#pragma unroll
+        for (int st = 0; st < 4; ++st) f.v[st] = (T)0;
+    }
+    return f;
+}
+// B[k][j = li] of a row-major block (a column walk)
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_cols(const T* blk, int li, int lg, bool on) {
+    Frag<T> f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) f.v[st] = blk[(4 * lg + st) * 17 + li];
+    if (!on) {                                                 // wave-uniform
+#pragma unroll
+        for (int st = 0; st < 4; ++st) f.v[st] = (T)0;
+    }
+    return f;
+}
+// B[k][j = li] = X_II[j][k] (k <= j): the leaf inverse TRANSPOSED, from the upper storage of diagonal block I
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_leafinv_T(const DiagShared<T>& sh, int I, int li, int lg) {
+    Frag<T> f;
+    const T* D = sh.S + LBLK(I, I);
+    const T dv = sh.dinv[16 * I + li];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int k = 4 * lg + st;
+        f.v[st] = pick3<T>(D[k * 17 + li], k < li, dv, k == li);
+    }
+    return f;
+}
+// B[k][j = li] = X_II[k][j] (j <= k): the leaf inverse itself
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_leafinv(const DiagShared<T>& sh, int I, int li, int lg, bool on) {
+    Frag<T> f;
+    const T* D = sh.S + LBLK(I, I);
+    const T dv = sh.dinv[16 * I + li];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int k = 4 * lg + st;
+        f.v[st] = pick3<T>(D[li * 17 + k], on && k > li, dv, on && k == li);
+    }
+    return f;
+}
+// B[k][j = li] = X_MJ[k][j] of the inverse under construction: a full block (M > J), the leaf inverse (M == J), zeros (M < J)
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_xblock(const DiagShared<T>& sh, int M, int J, int li, int lg) {
+    Frag<T> f;
+    const bool on = J <= M, leaf = J == M;
+    const T* blk = sh.S + (on ? LBLK(M, J) : 0);
+    const T dv = sh.dinv[16 * (on ? J : 0) + li];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int k = 4 * lg + st;
+        f.v[st] = pick3<T>(blk[leaf ? li * 17 + k : k * 17 + li], on && (!leaf || k > li), dv, leaf && k == li);
+    }
+    return f;
+}
+template <typename T>
+__device__ __forceinline__ void block_to_lds(T* dst, const typename MF<T>::acc_t& a, T sgn, int lane) {
+    const int li = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[MF<T>::row_of(lane, q) * 17 + li] = sgn * a[q];
+}
+
+// t (column-major enumeration of the 36 lower blocks) of diagonal block (I, I); block t belongs to bulk wave t % 3
+__device__ __forceinline__ int diag_diag_index(int I) { return I * 8 - I * (I - 1) / 2; }
+// The panel products P_b = A_bp X_pp^T (= L_bp, in place in the LDS image) of step p are shared out like this: block
+// p+1 goes to the wave that holds block (p+1, p+1); the others, b = p+2 .. 7, go round the three remaining waves (wave 0
+// included) in wave order, so each has at most two: b0 = p + 2 + slot and b0 + 3
+__device__ __forceinline__ int diag_panel_slot(int wave, int own) { return wave < own ? wave : wave - 1; }
+template <typename T>
+__device__ __forceinline__ void diag_two_panel_blocks(DiagShared<T>& sh, int p, int slot, int lane) {
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    const int li = lane & 15, lg = lane >> 4;
+    const int b0 = p + 2 + slot, b1 = b0 + 3;
+    if (b0 >= 8) return;
+    const bool two = b1 < 8;
+    T* A0 = sh.S + LBLK(b0, p);
+    T* A1 = sh.S + LBLK(two ? b1 : b0, p);
+    const Frag<T> x = frag_leafinv_T<T>(sh, p, li, lg);
+    const Frag<T> a0 = frag_rows<T>(A0, li, lg, true), a1 = frag_rows<T>(A1, li, lg, two);
+    acc_t c0, c1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c0[q] = c1[q] = (T)0;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        c0 = F::mfma(a0.v[st], x.v[st], c0);
+        c1 = F::mfma(a1.v[st], x.v[st], c1);
+    }
+    block_to_lds<T>(A0, c0, (T)1, lane);
+    if (two) block_to_lds<T>(A1, c1, (T)1, lane);
+}
+
+// ---- wave 0: the eight leaves, nothing else on its way.  Between leaf p and leaf p+1 it only sits out the short
+// section in which the others make block (p+1, p+1) final (and takes its share of the panel products).
+template <typename T>
+__device__ __forceinline__ void diag_leaf_wave(DiagShared<T>& sh, int lane) {
+    diag_barrier();                                            // B0: block column 0 is in LDS
+    for (int p = 0; p < 8; ++p) {
+        ALGP_STAMP(8 + 3 * p + 0);
+        diag_leaf<T>(sh, p, lane);
+        ALGP_STAMP(8 + 3 * p + 1);
+        diag_barrier();                                        // B2(p): L_pp, X_pp are in LDS
+        if (p < 6) diag_two_panel_blocks<T>(sh, p, diag_panel_slot(0, 1 + diag_diag_index(p + 1) % 3), lane);
+        ALGP_STAMP(8 + 3 * p + 2);
+        diag_barrier();                                        // Bx(p): block (p+1, p+1) is final and in LDS
+    }
+}
+
+// ---- waves 1-3 (w1 = 0..2): the 36 blocks of the trailing part in accumulator registers (12 each, NEGATED so that the
+// rank-16 updates are plain accumulating MFMAs), the panel products, the updates, the inverse and all global stores --
+// everything except the leaves, and all of it but a short section per panel while wave 0 runs the next leaf.
+// W1 is a template parameter so that, once the loops over the 12 blocks are unrolled, each block's coordinates are
+// constants (no index arrays in scalar registers, no address arithmetic at run time).
+template <typename T, int W1>
+__device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t lda, T* inv_out, int lane) {
+    constexpr int w1 = W1;
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    const int li = lane & 15, lg = lane >> 4;
+    acc_t acc[12];
+    int bis[12], bks[12];
+    // row_of(lane, q) = row_of(lane, 0) + rstep q: one 32-bit per-lane offset, the rest is wave-uniform (see the block movers)
+    const int rstep = F::row_of(0, 1) - F::row_of(0, 0);
+    const uint32_t vo = (uint32_t)F::row_of(lane, 0) * (uint32_t)lda + (uint32_t)li;
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+        diag_block_of(3 * u + w1, bis[u], bks[u]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[u][q] = -(A + (int64_t)(16 * bis[u] + rstep * q) * lda + 16 * bks[u])[vo];
+    }
+    // block column 0 -> LDS
+#pragma unroll
+    for (int u = 0; u < 12; ++u)
+        if (bks[u] == 0) block_to_lds<T>(sh.S + LBLK(bis[u], 0), acc[u], (T)-1, lane);
+    diag_barrier();                                            // B0
+    acc_t tacc[3];                                             // T_pJ = sum_K L_pK X_KJ of the inverse's row p, J = w1 + 3 m
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tacc[m][q] = (T)0;
+    for (int p = 0; p < 8; ++p) {
+        diag_barrier();                                        // B2(p): leaf p is done
+        // ================= the short section wave 0 waits for =================
+        const int own = p < 7 ? 1 + diag_diag_index(p + 1) % 3 : 0;
+        const bool mine = own == w1 + 1;
+        // inverse row p: X_pJ = -X_pp T_pJ (J = w1, w1+3, w1+6 below p) goes over L_pJ -- row p of L went to global memory in
+        // the previous shadow and every product that reads it is done.  A[i][k] = X_pp[i][k], k = the row of T this lane holds.
+        acc_t xo[3];
+        {
+            T xa[4];
+            const T* D = sh.S + LBLK(p, p);
+            const T dv = sh.dinv[16 * p + li];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int k = F::row_of(lane, st);
+                xa[st] = pick3<T>(D[k * 17 + li], k < li, dv, k == li);     // X_pp[li][k], k <= li
+            }
+            acc_t pc;                                          // the owner's panel product rides in the same batch (zeros otherwise)
+            const Frag<T> pa = frag_rows<T>(sh.S + LBLK(mine ? p + 1 : 7, p), li, lg, mine);
+            const Frag<T> px = frag_leafinv_T<T>(sh, p, li, lg);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pc[q] = (T)0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xo[m][q] = (T)0;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                pc = F::mfma(pa.v[st], px.v[st], pc);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) xo[m] = F::mfma(xa[st], tacc[m][st], xo[m]);
+            }
+            if (mine) block_to_lds<T>(sh.S + LBLK(p + 1, p), pc, (T)1, lane);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (w1 + 3 * m < p) block_to_lds<T>(sh.S + LBLK(p, w1 + 3 * m), xo[m], (T)-1, lane);
+        }
+        if (mine) {
+            // the last update of block (p+1, p+1) with the L_(p+1)p just written, then the block to LDS for the next leaf
+            const Frag<T> f = frag_rows<T>(sh.S + LBLK(p + 1, p), li, lg, true);
+#pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (bis[u] == p + 1 && bks[u] == p + 1) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) acc[u] = F::mfma(f.v[st], f.v[st], acc[u]);
+                    block_to_lds<T>(sh.S + LBLK(p + 1, p + 1), acc[u], (T)-1, lane);
+                }
+        } else if (p < 6) {
+            diag_two_panel_blocks<T>(sh, p, diag_panel_slot(w1 + 1, own), lane);
+        }
+        diag_barrier();                                        // Bx(p)
+        // ================= in the shadow of leaf p+1 =================
+        if (p < 7) {
+            // rank-16 update with panel p of every block right of it (block (p+1, p+1) has had its own), block by
+            // block (no LDS write in between: the compiler is free to run the next block's operand reads ahead)
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                if (!(bks[u] > p && !(bis[u] == p + 1 && bks[u] == p + 1))) continue;
+                const Frag<T> fa = frag_rows<T>(sh.S + LBLK(bis[u], p), li, lg, true);
+                const Frag<T> fb = frag_rows<T>(sh.S + LBLK(bks[u], p), li, lg, true);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) acc[u] = F::mfma(fa.v[st], fb.v[st], acc[u]);
+            }
+            // column p+1 below its diagonal block goes to LDS for the next panel products
+#pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (bks[u] == p + 1 && bis[u] > p + 1) block_to_lds<T>(sh.S + LBLK(bis[u], p + 1), acc[u], (T)-1, lane);
+            // finished parts go out: row p+1 of L left of its diagonal block
+            for (int J = w1; J <= p; J += 3)
+                store_block_rowmajor<T>(sh.S + LBLK(p + 1, J), A + (int64_t)(16 * (p + 1)) * lda + 16 * J, lda, lane);
+        }
+        // row p of the inverse and the diagonal block of L
+        {
+            T* xg = inv_out + (int64_t)(16 * p) * 128;
+            for (int J = w1; J < 8; J += 3) {
+                if (J < p) store_block_rowmajor<T>(sh.S + LBLK(p, J), xg + 16 * J, 128, lane);
+                else if (J == p) store_block_leafinv<T>(sh, p, xg + 16 * J, 128, lane);
+                else store_block_zero<T>(xg + 16 * J, 128, lane);
+            }
+            if (w1 == (p % 3)) store_block_lower<T>(sh.S + LBLK(p, p), A + (int64_t)(16 * p) * lda + 16 * p, lda, lane);
+        }
+        if (p < 7) {
+            // T_(p+1)J = sum_{M = J..p} L_(p+1)M X_MJ for the inverse's next row (X rows <= p are complete): M outermost,
+            // the three J of this wave as independent chains; a term that does not exist (M < J) multiplies zeros
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tacc[m][q] = (T)0;
+            for (int M = w1; M <= p; ++M) {
+                const Frag<T> fl = frag_rows<T>(sh.S + LBLK(p + 1, M), li, lg, true);
+                Frag<T> fx[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int J = w1 + 3 * m;
+                    fx[m] = frag_xblock<T>(sh, M, J, li, lg);
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) tacc[m] = F::mfma(fl.v[st], fx[m].v[st], tacc[m]);
+            }
+        }
+    }
 }
 
 // Factor the 128 x 128 block at A (leading dimension lda) in place and write its inverse (dense, 128 x 128, ld 128,
-// zeros above the diagonal) to inv_out.  Pipeline per 16-column step p (three barriers):
-//   [owners: block column p -> LDS] B1 [wave 0: leaf p | waves 1-3: row p of L -> global, row p-1 of X -> global,
-//   T_pJ = sum_K L_pK X_KJ for the inverse's row p] B2 [all: P_b = A_b X_pp^T; waves 1-3: X_pJ = -X_pp T_pJ] B3
-//   [all: rank-16 update of the register-resident blocks].
-// The inverse is complete one step after the factor: its rows ride in the shadow of the leaves.
-template <typename T>
+// zeros above the diagonal) to inv_out.  The eight 16 x 16 leaves are one dependency chain (every pivot waits for the
+// one before it), so wave 0 does nothing else; between leaf p and leaf p+1 lie only L_(p+1)p = A_(p+1)p X_pp^T, the
+// last rank-16 update of block (p+1, p+1) -- both by the wave that holds that block -- and two barriers.  Waves 1-3
+// do the rest in the shadow of the running leaf (see diag_bulk_wave): 48.9 -> see profiles us per block in fp64.
+// PIVOTS: instead of the block's log-determinant, the 128 pivots d_j go to pivots_out (as doubles) and the caller takes
+// the logarithms elsewhere -- the one-launch factorisation does: log() in here costs a reduction and two barriers on the
+// critical path of every column step, and its polynomial constants sat in registers across the whole kernel.
+template <typename T, bool PIVOTS = false>
 __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t lda, T* inv_out, double* logdet_acc,
-                                               bool logdet_atomic, int* info, int64_t block_row0) {
-    using F = MF<T>;
-    using acc_t = typename F::acc_t;
+                                               bool logdet_atomic, int* info, int64_t block_row0, double* pivots_out = nullptr) {
     const int tid = threadIdx.x;
-    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) sh.bad = 0;
+    if (tid == 0) sh.bad = 0;                                  // ordered before the leaves by barrier B0
     ALGP_STAMP(0);
-    // ---- load: global -> accumulator registers (negated), block t = 4u + wave of the column-major order ----
-    acc_t acc[9];
-    int bis[9], bks[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-        diag_block_of(4 * u + wave, bis[u], bks[u]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            acc[u][q] = -A[(int64_t)(16 * bis[u] + F::row_of(lane, q)) * lda + 16 * bks[u] + li];
-    }
-    ALGP_STAMP(1);
-    acc_t tacc[3];                                             // waves 1-3: T_pJ for J = wave - 1 + 3m
-    for (int p = 0; p < 8; ++p) {
-        // (1) owners put block column p into LDS
-#pragma unroll
-        for (int u = 0; u < 9; ++u)
-            if (bks[u] == p) {
-                T* dst = sh.S + LBLK(bis[u], p);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dst[F::row_of(lane, q) * 17 + li] = -acc[u][q];
-            }
-        __syncthreads();                                       // B1
-        if (p == 0) ALGP_STAMP(2);
-        ALGP_STAMP(8 + 6 * p + 0);
-        if (wave == 0) {
-            diag_leaf<T>(sh, p, lane);                         // (2)
-        } else {
-            const int w1 = wave - 1;
-            // finished parts go out while the leaf runs: row p of L left of the diagonal, the diagonal block of
-            // row p-1, row p-1 of the inverse
-            for (int J = w1; J < p; J += 3)
-                store_block_rowmajor<T>(sh.S + LBLK(p, J), A + (int64_t)(16 * p) * lda + 16 * J, lda, lane);
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int J = w1 + 3 * m;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) tacc[m][q] = (T)0;
-                if (J < p)
-                    for (int M = J; M < p; ++M) inv_accum_LX<T>(sh, p, M, J, tacc[m], li, lg);
-            }
-            if (p > 0) {
-                const int I = p - 1;
-                T* xo = inv_out + (int64_t)(16 * I) * 128;
-                for (int J = w1; J < 8; J += 3) {
-                    if (J < I) store_block_rowmajor<T>(sh.S + LBLK(I, J), xo + 16 * J, 128, lane);
-                    else if (J == I) store_block_leafinv<T>(sh, I, xo + 16 * J, 128, lane);
-                    else store_block_zero<T>(xo + 16 * J, 128, lane);
-                }
-                if (w1 == (I % 3))
-                    store_block_lower<T>(sh.S + LBLK(I, I), A + (int64_t)(16 * I) * lda + 16 * I, lda, lane);
-            }
-        }
-        if (p == 0) ALGP_STAMP(3);
-        ALGP_STAMP(8 + 6 * p + 1);
-        __syncthreads();                                       // B2
-        ALGP_STAMP(8 + 6 * p + 2);
-        // inverse row p: X_pJ = -X_pp T_pJ overwrites L_pJ (already stored; no later step reads row p of L)
-        if (wave > 0) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int J = wave - 1 + 3 * m;
-                if (J < p) {
-                    acc_t o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = (T)0;
-                    inv_accum_XT<T>(sh, p, p, tacc[m], o, lane, li);
-                    T* X = sh.S + LBLK(p, J);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) X[F::row_of(lane, q) * 17 + li] = -o[q];
-                }
-            }
-        }
-        if (p == 7) break;
-        // (3) P_b = A_b X_pp^T for the blocks below the leaf
-        for (int b = p + 1 + wave; b < 8; b += 4) {
-            T* Ab = sh.S + LBLK(b, p);
-            acc_t pacc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pacc[q] = (T)0;
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int k = 4 * st + lg;
-                pacc = F::mfma(Ab[li * 17 + k], leaf_inv_T<T>(sh, p, k, li), pacc);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Ab[F::row_of(lane, q) * 17 + li] = pacc[q];
-        }
-        ALGP_STAMP(8 + 6 * p + 3);
-        __syncthreads();                                       // B3
-        if (p == 0) ALGP_STAMP(4);
-        ALGP_STAMP(8 + 6 * p + 4);
-        // (4) rank-16 update of the register-resident blocks right of the panel: (-C) += P_bi P_bk^T
-#pragma unroll
-        for (int u = 0; u < 9; ++u)
-            if (bks[u] > p) {
-                const T* Pa = sh.S + LBLK(bis[u], p);
-                const T* Pb = sh.S + LBLK(bks[u], p);
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    acc[u] = F::mfma(Pa[li * 17 + 4 * st + lg], Pb[li * 17 + 4 * st + lg], acc[u]);
-            }
-        if (p == 0) ALGP_STAMP(5);
-        ALGP_STAMP(8 + 6 * p + 5);
-    }
+    if (wave == 0) diag_leaf_wave<T>(sh, lane);
+    else if (wave == 1) diag_bulk_wave<T, 0>(sh, A, lda, inv_out, lane);
+    else if (wave == 2) diag_bulk_wave<T, 1>(sh, A, lda, inv_out, lane);
+    else diag_bulk_wave<T, 2>(sh, A, lda, inv_out, lane);
     ALGP_STAMP(6);
-    __syncthreads();
-    // ---- tail: the last diagonal block of L, row 7 of the inverse, log-determinant ----
-    {
-        T* xo = inv_out + (int64_t)(16 * 7) * 128;
-        for (int J = wave; J < 8; J += 4) {
-            if (J < 7) store_block_rowmajor<T>(sh.S + LBLK(7, J), xo + 16 * J, 128, lane);
-            else store_block_leafinv<T>(sh, 7, xo + 16 * J, 128, lane);
-        }
-        if (wave == 2) store_block_lower<T>(sh.S + LBLK(7, 7), A + (int64_t)(16 * 7) * lda + 16 * 7, lda, lane);
-        double v = (tid < 128) ? log((double)sh.dd[tid]) : 0.0;
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((tid & 63) == 0) sh.red[tid >> 6] = v;
+    // every pivot was written before the last barrier of the loop; every store of this workgroup is issued when this
+    // returns (the caller drains them)
+    if (PIVOTS) {
+        if (tid < 128) pivots_out[tid] = (double)sh.dd[tid];
+        if (tid == 0 && sh.bad) atomicCAS(info, 0, (int)(block_row0 + sh.bad));
+        ALGP_STAMP(7);
+        diag_barrier();                                        // sh is free for the next block
+        return;
     }
+    double v = (tid < 128) ? log((double)sh.dd[tid]) : 0.0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((tid & 63) == 0) sh.red[tid >> 6] = v;
     __syncthreads();
     if (tid == 0) {
         const double ld = sh.red[0] + sh.red[1];

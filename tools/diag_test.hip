@@ -74,18 +74,16 @@ int run(const char* name, double tol) {
         if (rep == 3) {
             unsigned long long st[64];
             hipMemcpyFromSymbol(st, HIP_SYMBOL(algp::g_potrf_stamps), sizeof(st));
-            for (int k = 1; k < 8; ++k)
-                printf("  %-20s +%8llu cycles (cum %8llu)\n", names[k], st[k] - st[k - 1], st[k] - st[0]);
-            // per 16-column panel (thread 0 = wave 0): B1 -> leaf done -> B2 passed -> inverse row + P_b done -> B3 passed -> rank-16 update done
-            const char* ph[5] = {"leaf (wave 0)", "wait at B2", "inv row + P_b", "wait at B3", "rank-16 update"};
-            unsigned long long sums[5] = {0}, between = 0;
-            for (int p = 0; p < 7; ++p) {
-                for (int q = 0; q < 5; ++q) sums[q] += st[8 + 6 * p + q + 1] - st[8 + 6 * p + q];
-                between += st[8 + 6 * (p + 1)] - st[8 + 6 * p + 5];
+            printf("  whole block: %llu cycles\n", st[7] - st[0]);
+            // wave 0 per 16-column panel: leaf | barrier + its share of the panel products | barrier (next diagonal block final)
+            unsigned long long leaf = 0, crit = 0, bx = 0;
+            for (int p = 0; p < 8; ++p) {
+                leaf += st[8 + 3 * p + 1] - st[8 + 3 * p];
+                crit += st[8 + 3 * p + 2] - st[8 + 3 * p + 1];
+                if (p < 7) bx += st[8 + 3 * (p + 1)] - st[8 + 3 * p + 2];
             }
-            for (int q = 0; q < 5; ++q) printf("  panels 0-6, %-16s %8llu cycles\n", ph[q], sums[q]);
-            printf("  panels 0-6, update -> next B1 (column to LDS + barrier) %8llu cycles;  panel 7: leaf %llu, B2 %llu\n", between,
-                   st[8 + 42 + 1] - st[8 + 42], st[8 + 42 + 2] - st[8 + 42 + 1]);
+            printf("  8 leaves %llu cycles; B2 + panel products %llu; wait for the next diagonal block (7x) %llu; start -> first leaf %llu; last leaf done -> end %llu\n",
+                   leaf, crit, bx, st[8] - st[0], st[7] - st[8 + 3 * 7 + 1]);
         }
     }
     hipMemcpy(hL.data(), dA, sizeof(T) * n * lda, hipMemcpyDeviceToHost);
