@@ -111,6 +111,7 @@ struct algp_ctx {
     algp::DevBuf splitk;                 // partial products of split-K launches (skinny solves)
     std::vector<algp::DagCache> dag_cache;   // task lists of the dependency-driven Cholesky, per matrix size
     algp::DevBuf dag_state;              // its per-launch tile versions / control words / per-block log-determinants
+    algp::DevBuf trsv_ctrl;              // ticket + per-block flags of the one-launch forward substitution (potrf.hip)
     algp::DevBuf dag_stats;              // its in-kernel task accounting (while profiling is on), see algp_cholesky_task_stats
     int64_t acc_cols = 0, acc_M = -1;
     int64_t factor_rows_from_vt = 0;     // last factor update: rows of L taken from V^T instead of a triangular solve
@@ -282,6 +283,8 @@ int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T*
 // b <- L^-1 b (forward) and b <- L^-T b (backward) for one vector of length npad
 template <typename T>
 int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b, int64_t kb_start = 0);
+template <typename T>
+int trsv_forward2(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b0, T* b1, int64_t kb_start = 0);
 // u[k:] -= L[k:, 0:k] u[0:k] (and the same for w): resume two forward substitutions at row k
 template <typename T>
 int tail_gemv2_launch(algp_ctx* c, const T* L, int64_t ldl, int64_t k, int64_t npad, T* u, T* w);

@@ -376,21 +376,6 @@ __global__ __launch_bounds__(128) void diag_matvec_kernel(const T* inv, T* b) {
     b[t] = s;
 }
 
-// rows [0, mrem) of the panel P (mrem x 128, ld): out[r] -= dot(P[r][0:128], x)
-template <typename T>
-__global__ __launch_bounds__(256) void panel_gemv_kernel(const T* P, int64_t ld, int64_t mrem, const T* x, T* out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    const T x0 = x[2 * lane], x1 = x[2 * lane + 1];
-    for (int64_t r = wave; r < mrem; r += nw) {
-        const T* row = P + r * ld;
-        T s = row[2 * lane] * x0 + row[2 * lane + 1] * x1;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) out[r] -= s;
-    }
-}
-
 // columns [0, ncol) of the row panel R (128 x ncol, ld): out[cidx] -= sum_r R[r][cidx] * x[r]
 template <typename T>
 __global__ __launch_bounds__(256) void panel_gemv_t_kernel(const T* R, int64_t ld, int64_t ncol, const T* x, T* out) {
@@ -450,23 +435,134 @@ int tail_gemv2_launch(algp_ctx* c, const T* L, int64_t ldl, int64_t k, int64_t n
 template int tail_gemv2_launch<double>(algp_ctx*, const double*, int64_t, int64_t, int64_t, double*, double*);
 template int tail_gemv2_launch<float>(algp_ctx*, const float*, int64_t, int64_t, int64_t, float*, float*);
 
-template <typename T>
-int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b, int64_t kb_start) {
-    const int64_t nblk = npad / NB;
-    ProfScope ps(c, ALGP_PROF_TRSV, (double)npad * npad, sizeof(T) * 0.5 * (double)npad * npad);
-    for (int64_t kb = kb_start; kb < nblk; ++kb) {
-        hipLaunchKernelGGL((diag_matvec_kernel<T, false>), dim3(1), dim3(128), 0, c->cur, invD + kb * NB * NB,
-                           b + kb * NB);
-        const int64_t mrem = npad - (kb + 1) * NB;
-        if (mrem > 0) {
-            const int grid = (int)((mrem + 3) / 4 < 1024 ? (mrem + 3) / 4 : 1024);
-            hipLaunchKernelGGL(panel_gemv_kernel<T>, dim3(grid), dim3(256), 0, c->cur,
-                               L + (kb + 1) * NB * ldl + kb * NB, ldl, mrem, b + kb * NB, b + (kb + 1) * NB);
-        }
+// ---------------------------------------------------------------------------------------------
+// Forward substitution b <- L^-1 b as ONE launch (one or two right-hand sides at once).  The launch sequence above it
+// in round 2 -- a 128-thread diagonal kernel and a panel GEMV per block, ~160 launches at N = 10 000 -- spent 0.9 ms per
+// right-hand side on launch latency (every fit, and every commit of a pick another rank owns).
+// Workgroup i (numbered by an arrival ticket, so that the blocks it waits for are held by workgroups that already run:
+// no assumption about dispatch order or residency) owns block row i: it streams L_ij, j < i, as the z_j appear (a flag
+// per block; the L segment of block j+1 is loaded while block j is multiplied and flag j+1 is awaited), then multiplies
+// by the inverse of its diagonal block and publishes z_i write-through.  512 threads: four per row, 32 columns each.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NR>
+__global__ __launch_bounds__(512) void trsv_chain_kernel(const T* L, int64_t ld, const T* invD, T* b0, T* b1, int kb0, int nblk,
+                                                         int* ctrl) {
+    __shared__ T zs[NR][128];
+    __shared__ T red[NR][4][128];
+    __shared__ int s_i, s_ok;
+    const int tid = threadIdx.x, r = tid & 127, q = tid >> 7;
+    if (tid == 0) s_i = kb0 + atomicAdd(&ctrl[0], 1);
+    __syncthreads();
+    const int i = s_i;
+    if (i >= nblk) return;
+    int* flags = ctrl + 8;
+    T* bs[2] = {b0, b1};
+    T acc[NR];
+#pragma unroll
+    for (int v = 0; v < NR; ++v) acc[v] = (T)0;
+    const T* Lrow = L + ((int64_t)i * 128 + r) * ld + q * 32;
+    T cur[32], nxt[32];
+    if (kb0 < i) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) cur[e] = Lrow[(int64_t)kb0 * 128 + e];
     }
+    // the inverse of the diagonal block: this thread's 32 entries of row r, loaded long before they are needed
+    T xinv[32];
+    {
+        const T* X = invD + (int64_t)i * 128 * 128 + r * 128 + q * 32;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) xinv[e] = X[e];
+    }
+    for (int j = kb0; j < i; ++j) {
+        if (tid == 0) {
+            bool ok = false;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spins = 0;; ++spins) {
+                if (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = true; break; }
+                if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {       // 2 s at 100 MHz
+                    atomicCAS(&ctrl[1], 0, i + 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_ok) return;                                         // wave-uniform: the launch is being abandoned
+        // z_j was stored write-through and is read past this CU's L1 (sc1): no fence on either side
+        if (tid < 128) {
+#pragma unroll
+            for (int v = 0; v < NR; ++v) zs[v][tid] = __hip_atomic_load(bs[v] + (int64_t)j * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (j + 1 < i) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) nxt[e] = Lrow[(int64_t)(j + 1) * 128 + e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+#pragma unroll
+            for (int v = 0; v < NR; ++v) acc[v] += cur[e] * zs[v][q * 32 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 32; ++e) cur[e] = nxt[e];
+        __syncthreads();                                           // zs is rewritten in the next round
+    }
+    // x = b_i - sum_j L_ij z_j (the four column quarters of a row are added in a fixed order), then z_i = X_ii x
+#pragma unroll
+    for (int v = 0; v < NR; ++v) red[v][q][r] = acc[v];
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+        for (int v = 0; v < NR; ++v)
+            zs[v][tid] = bs[v][(int64_t)i * 128 + tid] - (((red[v][0][tid] + red[v][1][tid]) + red[v][2][tid]) + red[v][3][tid]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NR; ++v) {
+        T s = (T)0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) s += xinv[e] * zs[v][q * 32 + e];
+        red[v][q][r] = s;
+    }
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+        for (int v = 0; v < NR; ++v)
+            st_wt(bs[v] + (int64_t)i * 128 + tid, ((red[v][0][tid] + red[v][1][tid]) + red[v][2][tid]) + red[v][3][tid]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&flags[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+static int trsv_chain_launch(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b0, T* b1, int64_t kb_start) {
+    const int nblk = (int)(npad / NB), kb0 = (int)kb_start;
+    if (kb0 >= nblk) return ALGP_OK;
+    const size_t bytes = sizeof(int) * (size_t)(nblk + 8);
+    ALGP_TRY(ensure(c, c->trsv_ctrl, bytes));
+    ALGP_HIP(hipMemsetAsync(c->trsv_ctrl.p, 0, bytes, c->cur));
+    const int nr = b1 ? 2 : 1;
+    ProfScope ps(c, ALGP_PROF_TRSV, nr * (double)npad * npad, sizeof(T) * 0.5 * (double)npad * npad);
+    if (b1) hipLaunchKernelGGL((trsv_chain_kernel<T, 2>), dim3(nblk - kb0), dim3(512), 0, c->cur, L, ldl, invD, b0, b1, kb0, nblk, (int*)c->trsv_ctrl.p);
+    else hipLaunchKernelGGL((trsv_chain_kernel<T, 1>), dim3(nblk - kb0), dim3(512), 0, c->cur, L, ldl, invD, b0, (T*)nullptr, kb0, nblk, (int*)c->trsv_ctrl.p);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
+
+template <typename T>
+int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b, int64_t kb_start) {
+    return trsv_chain_launch<T>(c, L, npad, ldl, invD, b, (T*)nullptr, kb_start);
+}
+// two right-hand sides in the same pass over L
+template <typename T>
+int trsv_forward2(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b0, T* b1, int64_t kb_start) {
+    return trsv_chain_launch<T>(c, L, npad, ldl, invD, b0, b1, kb_start);
+}
+template int trsv_forward2<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, double*, double*, int64_t);
+template int trsv_forward2<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, float*, float*, int64_t);
 template <typename T>
 int trsv_backward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b) {
     const int64_t nblk = npad / NB;
