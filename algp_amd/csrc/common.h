@@ -181,7 +181,7 @@ int ensure(algp_ctx* c, DevBuf& b, size_t bytes);
 void prof_begin(algp_ctx* c, int klass, double flops, double bytes);
 void prof_end(algp_ctx* c);
 void prof_collect(algp_ctx* c);
-// un-nested wall-time span on the main stream (e.g. a whole factorisation that overlaps two streams)
+// un-nested wall-time span on the main stream (e.g. a whole candidate solve whose row chunks overlap on several streams)
 void prof_span_begin(algp_ctx* c, int klass, double flops, double bytes);
 void prof_span_end(algp_ctx* c);
 void prof_span_end_on(algp_ctx* c, hipStream_t st);
