@@ -58,6 +58,7 @@ template int trinv_diag_launch<float>(algp_ctx*, const float*, int64_t, float*);
 // tiles share each A row-panel through the XCD's L2 (TRSM).
 // ---------------------------------------------------------------------------------------------
 constexpr int WB = 512;
+constexpr int64_t TRSM_PUSH_TILES = 320;   // candidate solves of up to 320 x 128 rows run right-looking (trsm_rows_blocked)
 
 static hipEvent_t sync_event(algp_ctx* c, size_t i);
 template <typename T>
@@ -127,7 +128,7 @@ template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*
 //   inside J, 128 columns at a time: X_k <- (X_k - X_{J0:k} L_{k,J0:k}^T) inv(L_kk)^T
 template <typename T>
 static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                     int64_t ldl, const T* invD, int64_t col_start) {
+                     int64_t ldl, const T* invD, int64_t col_start, bool whole_solve) {
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
     if (mpad <= 32 * NB) {
         // A short X (a few test points): the left-looking order below would walk K up to npad inside
@@ -147,6 +148,64 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
                                            Xk + NB, ldx, Xk + NB, ldx, 0));
         }
         return ALGP_OK;
+    }
+    if (whole_solve && col_start == 0 && mpad <= TRSM_PUSH_TILES * NB) {     // (never a row chunk of a larger solve)
+        // A mid-sized X (a few thousand to ~40 000 rows: a rank's share of the candidates on 4-8 GPUs, a held-out set):
+        // the left-looking order below launches (rows/128) x 4 tiles per block column, each walking a K of up to npad --
+        // 132 tiles on 512 slots per row chunk at 12 500 rows (41 TFLOP/s fp64).  RIGHT-looking over 512-column
+        // blocks instead: solve a block (inside it left-looking, as below), then push it into ALL columns to its right
+        // with one K = 512 GEMM of (rows/128) x (columns left/128) tiles -- the machine is full until the last few
+        // blocks, at the price of one read + write of the trailing columns per block (rows x npad^2 / 512 elements in
+        // all: 20 GB at 12 500 x 10 000 fp64, 64 flop per byte).  Measured at N = 10 000, fp64 (left-looking -> this):
+        // 5 000 rows 18.1 -> 13.2 ms, 12 500 rows 30.6 -> 23.4 ms (41 -> 53 TFLOP/s), 25 000 rows 45.9 -> 42.7 ms; equal at
+        // 50 000 rows, where the three row-chunk streams of the left-looking order fill the machine as well.
+        // Two streams: the short launches that solve block J+1 (and the push of block J into block J+1 alone, which they
+        // wait for) run on the caller's stream BESIDE the big push of block J into the columns beyond, on a helper stream.
+        //   main:   I(J) . record a[J] . wait b[J-1] . Q(J) . I(J+1) ...      I = solve inside the block, Q = push into the next block
+        //   helper: wait a[J] . P(J) . record b[J]                            P = push into everything beyond the next block
+        // Every column block receives its pushes in ascending J (P(J-1) before Q(J), both before I(J+1)).
+        constexpr int64_t PW = WB;                                  // (1024-wide pushes: 25.2 ms at 12 500 rows, 41.9 at 25 000)
+        hipStream_t sa = c->cur, sb = (c->cur == c->stream && c->stream2) ? c->stream2 : nullptr;
+        int rc = ALGP_OK;
+        int64_t jb = 0;
+        for (int64_t j0 = 0; j0 < npad && rc == ALGP_OK; j0 += PW, ++jb) {
+            const int64_t w = (npad - j0 < PW) ? npad - j0 : PW, j1 = j0 + w;
+            T* Xj = X + j0;
+            for (int64_t k0 = j0; k0 < j1 && rc == ALGP_OK; k0 += NB) {
+                T* Xk = X + k0;
+                if (k0 > j0)
+                    rc = gemm_nt_launch<T>(c, klass, mpad, NB, k0 - j0, (T)-1, Xj, ldx, L + k0 * ldl + j0, ldl, (T)1, Xk, ldx, Xk,
+                                           ldx, 0);
+                if (rc == ALGP_OK)
+                    rc = gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, (T)0, nullptr, 0,
+                                           Xk, ldx, 0);
+            }
+            if (j1 >= npad || rc != ALGP_OK) break;
+            const int64_t wq = (npad - j1 < PW) ? npad - j1 : PW;           // width of the next block
+            if (sb) {
+                hipEvent_t ea = sync_event(c, 8 + 2 * (size_t)(jb & 3)), eb = sync_event(c, 9 + 2 * (size_t)(jb & 3));
+                hipEventRecord(ea, sa);
+                if (jb > 0) hipStreamWaitEvent(sa, sync_event(c, 9 + 2 * (size_t)((jb - 1) & 3)), 0);
+                rc = gemm_nt_launch<T>(c, klass, mpad, wq, w, (T)-1, Xj, ldx, L + j1 * ldl + j0, ldl, (T)1, X + j1, ldx, X + j1, ldx, 0);
+                if (rc == ALGP_OK && j1 + wq < npad) {
+                    hipStreamWaitEvent(sb, ea, 0);
+                    c->cur = sb;
+                    rc = gemm_nt_launch<T>(c, klass, mpad, npad - (j1 + wq), w, (T)-1, Xj, ldx, L + (j1 + wq) * ldl + j0, ldl, (T)1,
+                                           X + j1 + wq, ldx, X + j1 + wq, ldx, 0);
+                    c->cur = sa;
+                }
+                hipEventRecord(eb, sb);
+            } else {
+                rc = gemm_nt_launch<T>(c, klass, mpad, npad - j1, w, (T)-1, Xj, ldx, L + j1 * ldl + j0, ldl, (T)1, X + j1, ldx,
+                                       X + j1, ldx, 0);
+            }
+        }
+        if (sb) {                                                   // the caller's stream continues after the last push
+            hipEvent_t done = sync_event(c, 16);
+            hipEventRecord(done, sb);
+            hipStreamWaitEvent(sa, done, 0);
+        }
+        return rc;
     }
     const int64_t TWB = WB;                                     // outer block width
     for (int64_t j0 = 0; j0 < npad; j0 += TWB) {
@@ -218,8 +277,8 @@ template int trinv_upper<float>(algp_ctx*, int, float*, int64_t, int64_t, const 
 // traffic per solve at N = 10 000, M = 100 000 -- the big off-diagonal blocks of L fall out of the 4 MB L2s -- and removed.)
 template <typename T>
 static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                     int64_t ldl, const T* invD, int64_t col_start) {
-    return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start);
+                     int64_t ldl, const T* invD, int64_t col_start, bool whole_solve) {
+    return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, whole_solve);
 }
 
 static hipEvent_t sync_event(algp_ctx* c, size_t i) {
@@ -242,8 +301,9 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
     hipStream_t streams[4] = {c->stream, c->stream2, c->stream3, c->stream4};
     int nch = c->trsm_chunks < 1 ? 1 : (c->trsm_chunks > 4 ? 4 : c->trsm_chunks);
     while (nch > 1 && (!streams[nch - 1] || tiles < 32 * nch)) --nch;
+    if (col_start == 0 && tiles <= TRSM_PUSH_TILES) nch = 1;    // the right-looking order fills the machine by itself
     if (nch == 1 || c->cur != c->stream)
-        return trsm_rows<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start);
+        return trsm_rows<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, true);
     ALGP_HIP(hipEventRecord(sync_event(c, 0), streams[0]));
     int rc = ALGP_OK;
     int64_t r0 = 0;
@@ -251,7 +311,7 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
         const int64_t rows = (k == 0) ? mpad - r0 : (tiles / nch) * NB;
         if (k > 0) ALGP_HIP(hipStreamWaitEvent(streams[k], sync_event(c, 0), 0));
         c->cur = streams[k];
-        if (rc == ALGP_OK) rc = trsm_rows<T>(c, klass, X + r0 * ldx, rows, ldx, L, npad, ldl, invD, col_start);
+        if (rc == ALGP_OK) rc = trsm_rows<T>(c, klass, X + r0 * ldx, rows, ldx, L, npad, ldl, invD, col_start, false);
         r0 += rows;
     }
     c->cur = streams[0];

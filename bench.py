@@ -530,6 +530,41 @@ def main():
         finally:
             ctx.set_trsm_chunks(0)
 
+    emu = None
+    if rank == 0 and world == 1 and want != 'weak':
+        # What ONE rank of a 2 / 4 / 8-rank strong-scaling run does, measured on this GPU: the same train set, its share of the
+        # candidates (the first 1/n of the list), the same picks loop without the all-gather.  Every rank of such a run does
+        # this much work; what the emulation leaves out is the exchange (24 bytes per rank and pick), the commit of winners
+        # that another rank owns (one forward substitution each) and skew between ranks.
+        emu = {}
+        try:
+            w0, N0 = res['w'], res['N']
+            allc = np.arange(N0, N0 + res['total_c'])
+            for n in (2, 4, 8):
+                share = allc[:len(allc) // n]
+                ctx.set_candidates(share, prior_includes_noise=True)
+
+                def one():
+                    ctx.fit_and_solve()
+                    ctx.greedy(_hip.CRIT_ENTROPY, w0['static_std'], w0['mobile_std'], args.picks)
+                one()
+                ctx.prof_enable(True)
+                ctx.prof_reset()
+                ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    one()
+                ctx.sync()
+                ms = (time.perf_counter() - t0) / 3 * 1e3
+                fit = ctx.prof_get('cholesky')['ms'] / 3
+                tr = ctx.prof_get('trsm')['ms'] / 3
+                ctx.prof_enable(False)
+                emu[str(n)] = {'candidates_per_rank': int(len(share)), 'ms_per_step': ms, 'fit_ms': fit, 'trsm_ms': tr,
+                               'trsm_tflops': float(N0) ** 2 * len(share) / (tr * 1e-3) / 1e12 if tr > 0 else None}
+        except Exception as e:
+            print('bench: strong-scaling emulation failed: %s' % e, file=sys.stderr)
+            emu = None
+
     if rank == 0:
         K = args.steps
         w, N, total_c, prof, chol_stats = res['w'], res['N'], res['total_c'], res['prof'], res['chol_stats']
@@ -631,9 +666,18 @@ def main():
             'picks_last_step': res['picks'],
         }
         if world == 1:
-            out['strong_projection'] = {'note': 'projection from this run\'s stage split, NOT measured: every rank repeats the fit '
-                                                '(replicated_fit_ms), the candidate work divides by the number of ranks',
+            out['strong_projection'] = {'note': 'arithmetic on this run\'s stage split, NOT measured: every rank repeats the fit '
+                                                '(replicated_fit_ms), the candidate work is assumed to divide by the number of ranks '
+                                                '-- optimistic: a solve of 1/n of the candidates runs at a lower rate, see strong_emulation',
                                         'by_gpus': proj}
+            if emu:
+                for n, e in emu.items():
+                    e['speedup_vs_1'] = ms_step / e['ms_per_step']
+                    e['scoring_only_ms'] = max(e['ms_per_step'] - e['fit_ms'], 0.0)
+                    e['scoring_only_speedup_vs_1'] = sharded_ms / e['scoring_only_ms'] if e['scoring_only_ms'] > 0 else None
+                out['strong_emulation'] = {'note': 'MEASURED on this one GPU: the step of one rank of an n-rank strong-scaling run (same '
+                                                   'train set, 1/n of the candidates, same picks loop, no all-gather, no remote commits); '
+                                                   'an upper bound of what n GPUs can reach, not a multi-GPU measurement', 'by_gpus': emu}
         if weak is not None:
             out['weak_scaling'] = {'value': weak['total_c'] / (weak['elapsed'] / K), 'unit': 'candidates/s',
                                    'ms_per_step': 1e3 * weak['elapsed'] / K,
