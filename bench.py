@@ -363,6 +363,8 @@ def main():
     ap.add_argument('--picks', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the C3 / C5 / MI legs (they run after the timed region)')
+    ap.add_argument('--no-emulation', action='store_true', help='skip the one-stream leg and the strong-scaling emulation (profiling runs: '
+                    'only the workload\'s own launches in the trace)')
     ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed/RCCL path even with one rank')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo only for rehearsing several ranks on ONE card (RCCL refuses duplicate devices)')
@@ -511,7 +513,7 @@ def main():
         args.scaling = 'strong'
 
     serial = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_emulation:
         # the same solve with ONE row-chunk stream: the launches run back to back, so the sum of their own durations is
         # the GEMM kernel's rate without help from overlapping another stream's tail (what a --pmc pass also measures)
         try:
@@ -531,7 +533,7 @@ def main():
             ctx.set_trsm_chunks(0)
 
     emu = None
-    if rank == 0 and world == 1 and want != 'weak':
+    if rank == 0 and world == 1 and want != 'weak' and not args.no_emulation:
         # What ONE rank of a 2 / 4 / 8-rank strong-scaling run does, measured on this GPU: the same train set, its share of the
         # candidates (the first 1/n of the list), the same picks loop without the all-gather.  Every rank of such a run does
         # this much work; what the emulation leaves out is the exchange (24 bytes per rank and pick), the commit of winners

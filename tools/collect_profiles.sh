@@ -5,7 +5,7 @@
 set -e -o pipefail
 DT=${1:-f64}
 OUT=${2:-gpurun_out/prof_r03_$DT}
-ARGS="bench.py --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+ARGS="bench.py --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-emulation"
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
 python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err

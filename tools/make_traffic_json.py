@@ -17,7 +17,7 @@ spec.loader.exec_module(bench)
 
 out = {'sources_sha16': bench.sources_sha16(),
        'commit': subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=REPO, capture_output=True, text=True).stdout.strip() or None,
-       'command': 'bench.py --dtype <dt> --steps 3 --warmup 1 --no-cpu-baseline --no-extras (10 candidate solves per run)',
+       'command': 'bench.py --dtype <dt> --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-emulation (7 candidate solves per run: 1 warm-up + 3 timed with the stage timers + 3 without)',
        'note': 'bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): gfx950 tallies the 128-byte requests of wide streaming reads at 64 '
                'bytes (MI355X_MICROARCH.md, HBM); separate --pmc passes; FETCH/WRITE count the L2\'s fabric-side requests, so '
                'Infinity-Cache hits are included.  WRITE_SIZE is calibrated for 16-byte-per-lane streaming stores; the Cholesky\'s '
@@ -32,7 +32,7 @@ for dt, path in (('f64', sys.argv[1]), ('f32', sys.argv[2])):
         n = g.get('n_FETCH_SIZE', g.get('calls', 0))
         out['gemm_nt_%s_bytes_per_launch' % dt] = g['hbm_bytes_per_launch']
         out['gemm_nt_%s_launches_counted' % dt] = n
-        out['bytes_per_solve_%s' % dt] = g['hbm_bytes_per_launch'] * n / 10.0
+        out['bytes_per_solve_%s' % dt] = g['hbm_bytes_per_launch'] * n / 7.0
         out['gemm_nt_%s_gb_per_s_in_counter_pass' % dt] = g.get('hbm_gb_per_s')
         out['gemm_nt_%s_mfma_busy_pct' % dt] = g.get('mfma_busy_pct')
     d = bk.get('chol_dag_kernel<%s>' % sym)
