@@ -563,6 +563,7 @@ struct DagSchedule {
     float makespan = 0;                                        // of the simulation, microseconds
 };
 
+constexpr int DAG_FAR8 = 4, DAG_FAR16 = 16;                    // see the batches in dag_build_schedule
 static int batched_until(int j, int W) {                       // columns [0, kf) of tile column j arrive in batches of 4
     if (j < W) return 0;
     return 4 * ((j - W) / 4);
@@ -657,6 +658,8 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             edge(last_writer[(size_t)i * nt + k], tr);
             trsm[(size_t)i * nt + k] = tr;
             edge_after_start(last_writer[(size_t)i * nt + (k + 1)], tr);
+            edge_after_start(trsm[(size_t)(k + 1) * nt + k], tr);           // ... and after the team's TRSM(k+1,k) has started:
+                                                                             // every ticketed ancestor of L_(k+1)k is then done
             const int u = add(DAG_CHAIN, i, k + 1, k, k + 1, D_OP + 0.5f * D_OVH);
             nodes[u].on_chain = true;
             edge(tr, u);
@@ -679,8 +682,23 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
                 for (int i = j; i < nt; ++i)
                     if (i > k + 2 && j != k + 1) upd(i, j, k, k + 1);   // single step (rows k+1, k+2 are the team's,
                                                                              // column k+1 went with the TRSM: DAG_TU)
-            } else if ((k + 1) % 4 == 0) {
-                for (int i = j; i < nt; ++i) upd(i, j, k - 3, k + 1);        // batch of four
+            } else {
+                // Batches of four column steps (K = 512) next to the window, of eight (K = 1024) from DAG_FAR8 steps before
+                // it, of sixteen (K = 2048) from DAG_FAR16 steps before that: one read + write of the tile and one ticket /
+                // wait / publish per batch.  Measured at N = 10 000 (fours only -> this): 7.62 -> 7.35 ms in fp64, 5.14 ->
+                // 4.80 ms in fp32, whose tile products are half as long and so feel the fixed cost per task twice as much
+                // (sixteens everywhere: 8.15 ms -- a batch can only start when its last column is solved).
+                const int kf8 = std::max(0, 8 * ((kf - DAG_FAR8) / 8));      // [kf16, kf8) in eights, [kf8, kf) in fours
+                const int kf16 = std::max(0, 16 * ((kf8 - DAG_FAR16) / 16)); // [0, kf16) in sixteens
+                if (k < kf16) {
+                    if ((k + 1) % 16 == 0)
+                        for (int i = j; i < nt; ++i) upd(i, j, k - 15, k + 1);
+                } else if (k < kf8) {
+                    if ((k + 1) % 8 == 0)
+                        for (int i = j; i < nt; ++i) upd(i, j, k - 7, k + 1);
+                } else if ((k + 1) % 4 == 0) {
+                    for (int i = j; i < nt; ++i) upd(i, j, k - 3, k + 1);
+                }
             }
         }
     }
@@ -805,7 +823,8 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
 template <typename T>
 int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
     const int nt = (int)(npad / NB);
-    const int W = 4;     // fine (K=128) steps next to a tile's own column; >= 2: the team owns rows k+1, k+2 (2..8 measured: within 1 %)
+    const int W = 2;     // fine (K=128) steps next to a tile's own column; >= 2: the team owns rows k+1, k+2.  With the K = 1024 / 2048
+                         // batches of round 3: W = 2 / 3 / 4 / 6 -> 7.28 / 7.32 / 7.28 / 7.53 ms in fp64, 4.49 / 4.58 / 4.86 / 5.10 ms in fp32
     DagCache* dc = nullptr;
     for (auto& e : c->dag_cache)
         if (e.nt == nt) dc = &e;
