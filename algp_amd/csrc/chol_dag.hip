@@ -73,12 +73,15 @@ __device__ unsigned long long g_dag_chain[16 * 1024];         // per chain step:
 #define DAG_CHAINT(k, slot) do { if (threadIdx.x == 0 && (k) < 1024) g_dag_chain[16 * (k) + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 __device__ int g_dag_who[262144];
 #define DAG_TRACE(t, slot) do { if (threadIdx.x == 0 && (t) < 262144) g_dag_trace[4 * (t) + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_dag_phase[8];                 // K = 128 tile products: ticks until the C loads are issued / main loop / until the stores are issued (x 10^6) + drain, count
+#define DAG_PHASE(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #define DAG_WHO(t) do { if (threadIdx.x == 0 && (t) < 262144) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_dag_who[t] = (int)((blockIdx.x << 4) | (xcc & 15)); } } while (0)
 #else
 #define DAG_DBG(slot, val) do { } while (0)
 #define DAG_TRACE(t, slot) do { } while (0)
 #define DAG_WHO(t) do { } while (0)
 #define DAG_CHAINT(k, slot) do { } while (0)
+#define DAG_PHASE(var) do { } while (0)
 #endif
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -217,6 +220,7 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     T* Cij = g.L + (int64_t)ti * 128 * g.ld + (int64_t)tj * 128;
+    DAG_PHASE(ph0);
     acc_t acc[4][4];
     const T* A0;
     const T* B0;
@@ -248,7 +252,9 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
         ldb = 128;
         nkt = 128 / (4 * F::EPC);
     }
+    DAG_PHASE(ph1);
     tile_mainloop<T>(smem, A0, g.ld, B0, ldb, nkt, acc);
+    DAG_PHASE(ph2);
     const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -258,6 +264,21 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
 #pragma unroll
             for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * g.ld + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
         }
+#ifdef ALGP_DAG_DEBUG
+    // Where a K = 128 product spends its time (tools/dag_test.hip prints the means): "issuing" the 64 loads / 64 stores
+    // of a lane takes 3-5 us each, and that is the memory system's back-pressure, not the instruction count -- with
+    // the tile moved in 16-byte pieces (operands of the MFMA exchanged so that a lane holds row pieces) the stores took
+    // as long (fp32) or twice as long (fp64: half-line pieces) and the loads, no longer overlapped, 12-15 us.
+    DAG_PHASE(ph3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DAG_PHASE(ph4);
+    if (threadIdx.x == 0 && nkt == 128 / (4 * F::EPC)) {
+        atomicAdd(&g_dag_phase[upd ? 0 : 4], ph1 - ph0);
+        atomicAdd(&g_dag_phase[upd ? 1 : 5], ph2 - ph1);
+        atomicAdd(&g_dag_phase[upd ? 2 : 6], (ph3 - ph2) * 1000000ull + (ph4 - ph3));
+        atomicAdd(&g_dag_phase[upd ? 3 : 7], 1ull);
+    }
+#endif
 }
 
 // One of `parts` workgroups that share a tile publishes its part: drained as in dag_publish, then an agent-scope add
