@@ -4,9 +4,9 @@
 // right-looking factorisation of potrf.hip is a chain of short launches (diagonal block on one workgroup,
 // K = 128 panel launches, one K = 512 update per 512 columns): at N = 10 000 the chip is mostly idle
 // (19.7 TFLOP/s, round 1).  Here the same arithmetic is a list of tile tasks over 128 x 128 tiles
-//     CHAIN(k)          L_kk = chol(S_kk), X_kk = inv(L_kk) (diag.h), then the two tile products the next
-//                       diagonal block waits for: TRSM(k+1,k) and UPD(k+1,k+1,k,k+1) -- all steps k by ONE workgroup
-//                       (the first to arrive), with no hand-off in between and its CU to itself
+//     CHAIN(k)          L_kk = chol(S_kk), X_kk = inv(L_kk) (diag.h) by the team's leader (the first workgroup to arrive,
+//                       its CU to itself), then the two tile products the next diagonal block waits for, TRSM(k+1,k)
+//                       and UPD(k+1,k+1,k,k+1), in 32-row strips by the team's four helpers (see the kernel)
 //     TRSM(i,k)         L_ik = S_ik X_kk^T                                   (MFMA tile product, K = 128)
 //     UPD(i,j,k0,k1)    S_ij -= L_i,[k0,k1) L_j,[k0,k1)^T                    (MFMA tile product, K = 128 (k1-k0))
 //     TU(i,k)           TRSM(i,k), then UPD(i,k+1,k,k+1) by the same workgroup: every row's step-to-step recurrence
@@ -18,9 +18,10 @@
 // as the chip holds workgroups), so look-ahead happens by itself: the diagonal chain runs ahead while the
 // K = 512 updates of older block columns fill every other workgroup.
 // Updates of a tile by the W + (0..3) columns just left of it are single K = 128 steps (they sit on or near
-// the critical path); everything older is applied in K = 512 batches (one read + one write of the tile per 512
-// columns keeps the update MFMA-bound instead of HBM-bound).  Each tile receives its updates in ascending k,
-// so the result is bitwise reproducible and independent of the schedule.
+// the critical path); everything older is applied in batches -- K = 512 next to that window, K = 1024 and K = 2048
+// further back (dag_build_schedule): one read + one write of the tile and one ticket / wait / publish per batch
+// keeps the update MFMA-bound instead of bound by the tile's own traffic.  Each tile receives its updates in
+// ascending k, so the result is bitwise reproducible and independent of the schedule.
 // Hand-off between workgroups (MI355X: per-XCD L2s that are not coherent with each other, per-CU L1s): producer =
 // every tile element is stored WRITE-THROUGH (sc1: nothing stays dirty in the XCD's L2, so no L2 write-back is needed
 // before the flag -- a release fence writes back every dirty line of the XCD, and with 64 workgroups per XCD writing
