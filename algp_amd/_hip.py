@@ -22,7 +22,7 @@ KERNEL_RBF, KERNEL_MATERN15 = 0, 1
 CRIT_ENTROPY, CRIT_MUTUAL_INFORMATION = 0, 1
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_OOM, ERR_STATE, ERR_NO_DEVICE = range(7)
 PROF = dict(kmat=0, gemm_chol=1, gemm_trsm=2, potrf_diag=3, trsv=4, rows=5, score=6, gemm_other=7, cholesky=8, trsm=9,
-            gemm_chol_update=10, chol_dag=11)
+            gemm_chol_update=10, chol_dag=11, dag_panel=12)
 
 _c_ctx = C.c_void_p
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)   # algp_allgather_fn

@@ -151,16 +151,6 @@ hipEvent_t sync_event_api(algp_ctx* c, size_t i) {
     return c->sync_events[i];
 }
 
-constexpr int SC_LOGDET = 0;     // slots (doubles) of ctx->scal
-constexpr int SC_INFO = 1;       // int stored in a double slot
-constexpr int SC_AUXLOGDET = 2;
-constexpr int SC_AUXINFO = 3;
-constexpr int SC_AMAXV = 4;
-constexpr int SC_AMAXI = 5;
-constexpr int SC_PROBE = 6;
-constexpr int SC_COMMIT = 8;     // (d_c, scale) of the pick being committed
-constexpr int SC_AMAXF = 10;     // fresh[argmax] of the lazy greedy
-constexpr int SC_COUNT = 32;
 
 KmatSrc make_src(algp_ctx* c) {
     KmatSrc s;
@@ -177,6 +167,23 @@ KmatSrc make_src(algp_ctx* c) {
 int sync(algp_ctx* c) {
     ALGP_HIP(hipStreamSynchronize(c->stream));
     c->n_syncs++;
+    return ALGP_OK;
+}
+
+// A synchronisation that also reads the sticky stall word (scal[SC_STALL]): one of the one-launch kernels that hand data
+// between workgroups (forward / backward substitution, the solve-only task list) ran into its spin limit and abandoned
+// its work since the word was last read -- whatever it was producing is incomplete.  The word is cleared again.
+int sync_checked(algp_ctx* c, const char* what) {
+    int stall = 0;
+    int* d = (int*)((double*)c->scal.p + SC_STALL);
+    ALGP_HIP(hipMemcpyAsync(&stall, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    ALGP_HIP(hipStreamSynchronize(c->stream));
+    c->n_syncs++;
+    if (stall != 0) {
+        hipMemsetAsync(d, 0, sizeof(double), c->stream);
+        return fail(c, ALGP_ERR_HIP, std::string(what) + ": a one-launch kernel stalled (a hand-off between its workgroups never "
+                                     "arrived within the spin limit); the result is incomplete");
+    }
     return ALGP_OK;
 }
 
@@ -307,13 +314,32 @@ struct Impl {
         return ALGP_OK;
     }
 
+    // Rows that ride along with a factorisation as extra block rows of its task list (chol_dag.hip): P <- P L^-T comes out
+    // of the same launch.  done: the launch took them (otherwise the caller solves them afterwards).
+    struct Panel {
+        T* P;
+        int64_t ldp, mpad;
+        int mode;                  // 1: dense rows (the candidates' B^T), 2: the identity (-> L^-T)
+        bool done;
+    };
+    static bool panel_fits(int64_t npad, int64_t mpad) {
+        const int64_t nt = npad / NB, mt = mpad / NB;
+        return dag_enabled() && nt >= DAG_MIN_TILES && nt <= DAG_MAX_TILES && mt >= 1 && mt <= DAG_MAX_PANEL_TILES;
+    }
+
     // factor an npad x npad matrix already resident in A; returns logdet; NOT_PD -> error with pivot
     static int factor_resident(algp_ctx* c, T* A, int64_t n, int64_t npad, T* invD, int slot_logdet, int slot_info,
-                               double* logdet, int64_t ld = 0, int64_t pivot_offset = 0) {
+                               double* logdet, int64_t ld = 0, int64_t pivot_offset = 0, Panel* panel = nullptr) {
         if (ld == 0) ld = npad;
         double* sc = (double*)c->scal.p;
         ALGP_HIP(hipMemsetAsync(sc + slot_logdet, 0, 2 * sizeof(double), c->stream));
-        ALGP_TRY(cholesky_blocked<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info)));
+        if (panel && panel_fits(npad, panel->mpad)) {
+            ALGP_TRY(cholesky_dag_panel<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info), panel->P, panel->ldp,
+                                           panel->mpad, panel->mode));
+            panel->done = true;
+        } else {
+            ALGP_TRY(cholesky_blocked<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info)));
+        }
         double host[2];
         ALGP_HIP(hipMemcpyAsync(host, sc + slot_logdet, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         ALGP_TRY(sync(c));
@@ -404,7 +430,7 @@ struct Impl {
         return true;
     }
 
-    static int factorize(algp_ctx* c, int incremental) {
+    static int factorize(algp_ctx* c, int incremental, Panel* panel = nullptr) {
         const int64_t N = c->N, Npad = c->Npad;
         int64_t keep = 0, p0 = 0;                                // rows of the resident factor to keep; unchanged leading rows
         if (incremental && c->factored && c->fact_hyp_stamp == c->hyp_stamp && c->Lld > 0) {
@@ -427,7 +453,7 @@ struct Impl {
             frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p, N, Npad, (const int64_t*)c->Aidx.p, N, Npad,
                                  (const T*)c->varA.p, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->L), ld);
             if (frc == ALGP_OK)
-                frc = factor_resident(c, p(c->L), N, Npad, p(c->invD), SC_LOGDET, SC_INFO, &ld_total, ld);
+                frc = factor_resident(c, p(c->L), N, Npad, p(c->invD), SC_LOGDET, SC_INFO, &ld_total, ld, 0, panel);
         } else {
             const int64_t Nb = keep, R = Npad - Nb;
             T* rows = p(c->L) + Nb * ld;
@@ -616,8 +642,15 @@ struct Impl {
     // were solved against rows of the factor that are unchanged (same leading train rows, same
     // hyper-parameters, same candidate list) are kept and only the trailing column blocks are solved.
     // `alive` (M bytes, may be null) disables candidates (sites that became static-sampled).
-    static int solve_candidates(algp_ctx* c, int incremental, const unsigned char* alive_host) {
-        if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "solve_candidates: call algp_factorize first");
+    // Three parts, so that algp_fit_and_solve can put the factorisation between the first two and let the rows of B^T
+    // ride along in its launch: solve_prepare (buffers, candidate kinds, B^T), the solve itself, solve_finish (row
+    // statistics, bookkeeping).
+    struct SolvePlan {
+        int64_t keep = 0;                    // leading columns of V^T that stay
+        std::vector<int> kind;               // per candidate: its train row (a unit right-hand side) or -1
+        std::vector<int64_t> became_unit;
+    };
+    static int solve_prepare(algp_ctx* c, int incremental, SolvePlan& pl) {
         const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad;
         const int64_t ldv = Npad + MAX_APPEND;
         int64_t keep = 0;
@@ -629,10 +662,12 @@ struct Impl {
             keep = p0 / NB * NB;
         }
         // candidate kinds under the current train set
-        std::vector<int> kind(Mpad, -1);
+        std::vector<int>& kind = pl.kind;
+        kind.assign(Mpad, -1);
         if (c->prior_noise)
             for (int64_t j = 0; j < M; ++j) kind[j] = (int)c->pos_in_train[c->cand_idx[j]];
-        std::vector<int64_t> became_unit;
+        std::vector<int64_t>& became_unit = pl.became_unit;
+        became_unit.clear();
         if (keep > 0) {
             // a kept column block is only valid for a row whose right-hand side is unchanged:
             //  - ordinary -> unit row e_pos with pos >= keep: the solution is zero before pos: zero the kept part;
@@ -645,6 +680,7 @@ struct Impl {
             }
             if (keep == 0) became_unit.clear();
         }
+        pl.keep = keep;
         c->solved = false;
         if (!c->Vt.p || c->ldv_cap < ldv || (keep == 0 && !incremental && c->ldv_cap != ldv) ||
             c->Vt.cap < sizeof(T) * Mpad * c->ldv_cap) {
@@ -685,14 +721,30 @@ struct Impl {
         KmatSrc s = make_src(c);
         // B^T: row j = C[cand_j, A] (ordinary) or e_pos (train-site candidate); zero padding.
         // Only columns >= keep are (re)generated and solved.
-        ALGP_TRY(kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Aidx.p + keep, N - keep,
-                                ldv - keep, nullptr, 0, c->prior_noise ? (const int*)c->ckind.p : nullptr, 0,
-                                p(c->Vt) + keep, ldc, 0, keep));
+        return kmat_launch<T>(c, s, (const int64_t*)c->Cidx.p, M, Mpad, (const int64_t*)c->Aidx.p + keep, N - keep,
+                              ldv - keep, nullptr, 0, c->prior_noise ? (const int*)c->ckind.p : nullptr, 0,
+                              p(c->Vt) + keep, ldc, 0, keep);
+    }
+
+    // the solve proper, against the resident factor.  A from-scratch solve of 33 .. 320 tile rows (a rank's share of the
+    // candidates on 4-8 GPUs, a held-out set) runs as ONE task-list launch (chol_dag.hip without the factorisation's
+    // own tasks; $ALGP_SOLVE_DAG=0: the launch sequences of potrf.hip); everything else is trsm_blocked.
+    static int solve_run(algp_ctx* c, const SolvePlan& pl) {
+        static const bool solve_dag_on = !(getenv("ALGP_SOLVE_DAG") && atoi(getenv("ALGP_SOLVE_DAG")) == 0);
+        const int64_t Npad = c->Npad, Mpad = c->Mpad, ldc = c->ldv, keep = pl.keep;
         prof_span_begin(c, ALGP_PROF_TRSM, (double)(Npad - keep) * (double)(Npad + keep) * (double)Mpad,
                         sizeof(T) * (double)Mpad * (double)Npad);
-        int trc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), Npad, c->Lld, p(c->invD), keep);
+        int trc;
+        if (solve_dag_on && keep == 0 && Mpad / NB > 32 && panel_fits(Npad, Mpad) && c->cur == c->stream)
+            trc = solve_dag_panel<T>(c, p(c->L), Npad, c->Lld, p(c->invD), (int*)((double*)c->scal.p + SC_STALL), p(c->Vt), ldc, Mpad, 1);
+        else
+            trc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), Npad, c->Lld, p(c->invD), keep);
         prof_span_end(c);
-        ALGP_TRY(trc);
+        return trc;
+    }
+
+    static int solve_finish(algp_ctx* c, int incremental, const unsigned char* alive_host, const SolvePlan& pl) {
+        const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad, ldc = c->ldv, keep = pl.keep;
         T* ss = p(c->tvec);
         T* dot = ss + Mpad;
         if (incremental && c->uw_rows == N && c->uvec.p && c->wvec.p) {
@@ -708,7 +760,7 @@ struct Impl {
             }
             T* acc = p(c->acc3);
             T* tmp = acc + 3 * Mpad;
-            for (int64_t j : became_unit)                                 // their kept columns were zeroed above
+            for (int64_t j : pl.became_unit)                              // their kept columns were zeroed above
                 for (int q = 0; q < 3; ++q) ALGP_HIP(hipMemsetAsync(acc + q * Mpad + j, 0, sizeof(T), c->stream));
             const int64_t fin = N / NB * NB;                              // column blocks no later append can touch
             if (fin > c->acc_cols)
@@ -728,7 +780,7 @@ struct Impl {
                                          c->cextra.p ? (const T*)c->cextra.p : nullptr, ss, dot, (T)c->ybar, p(c->dstat),
                                          p(c->mu), (unsigned char*)c->alive.p));
         if (alive_host) ALGP_HIP(hipMemcpyAsync(c->alive.p, alive_host, M, hipMemcpyHostToDevice, c->stream));
-        ALGP_TRY(sync(c));
+        ALGP_TRY(sync_checked(c, "solve_candidates"));
         c->ncols = Npad;
         c->picks.clear();
         c->mi_valid = false;
@@ -737,7 +789,7 @@ struct Impl {
         c->vt_fact_idx = c->fact_idx;
         c->vt_fact_var = c->fact_var;
         c->vt_cand_idx = c->cand_idx;
-        c->vt_kind.assign(kind.begin(), kind.begin() + M);
+        c->vt_kind.assign(pl.kind.begin(), pl.kind.begin() + M);
         c->vt_hyp_stamp = c->hyp_stamp;
         c->vt_prior_noise = c->prior_noise;
         c->vt_has_extra = c->cextra.p != nullptr;
@@ -745,13 +797,34 @@ struct Impl {
         return ALGP_OK;
     }
 
-    // GP-fit + candidate solve of one planning step (bench.py's step): the two phases back to back.  Overlapping the
-    // factorisation with the candidate solve on separate streams was measured in round 1 (207 vs 193 ms/step: the
-    // factorisation's short dependent launches queue behind multi-millisecond GEMM workgroups) and removed; the
-    // factorisation is now a single dependency-driven launch (chol_dag.hip).
+    static int solve_candidates(algp_ctx* c, int incremental, const unsigned char* alive_host) {
+        if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "solve_candidates: call algp_factorize first");
+        SolvePlan pl;
+        ALGP_TRY(solve_prepare(c, incremental, pl));
+        ALGP_TRY(solve_run(c, pl));
+        return solve_finish(c, incremental, alive_host, pl);
+    }
+
+    // GP-fit + candidate solve of one planning step (bench.py's step).  Up to 320 x 128 candidate rows (a rank's share on
+    // 4-8 GPUs) the two are ONE launch: the rows of B^T are extra block rows of the factorisation's task list (TRSM / UPD
+    // tasks without a diagonal), so V^T = B^T L^-T comes out of the launch that factors S -- the candidates' tile products
+    // fill the machine while the diagonal chain alone would leave it idle, and the 140 short launches of a separate
+    // mid-sized solve disappear ($ALGP_FOLD=0: the two phases back to back).  Larger candidate sets keep the two phases:
+    // the factorisation, then the three-stream sweep of potrf.hip, which wins from ~40 000 rows on.  (Overlapping the two
+    // as separate launch sequences on streams was measured in round 1 -- 207 vs 193 ms/step -- and removed.)
     static int fit_and_solve(algp_ctx* c) {
-        ALGP_TRY(factorize(c, 0));
-        return solve_candidates(c, 0, nullptr);
+        static const bool fold_on = !(getenv("ALGP_FOLD") && atoi(getenv("ALGP_FOLD")) == 0);
+        if (!fold_on || c->M == 0 || !panel_fits(c->Npad, c->Mpad)) {
+            ALGP_TRY(factorize(c, 0));
+            return solve_candidates(c, 0, nullptr);
+        }
+        c->factored = false;
+        SolvePlan pl;
+        ALGP_TRY(solve_prepare(c, 0, pl));                           // B^T is in place before the launch that consumes it
+        Panel pn{p(c->Vt), c->ldv, c->Mpad, 1, false};
+        ALGP_TRY(factorize(c, 0, &pn));
+        if (!pn.done) ALGP_TRY(solve_run(c, pl));
+        return solve_finish(c, 0, nullptr, pl);
     }
 
     static int get_posterior(algp_ctx* c, void* mu, void* var) {

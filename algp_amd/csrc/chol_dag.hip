@@ -51,9 +51,12 @@ struct DagArgs {
     T* L;
     int64_t ld;
     T* invD;
+    T* P;                                                      // the row panel below the factor (tile rows nt .. nt+mt-1), or null
+    int64_t ldp;
+    int no_team;                                               // solve-only list: L is final, every workgroup draws tickets
     const DagTask* tasks;
     int ntasks, nt;
-    int* ver;                                                  // nt x nt tile versions (number of column steps applied)
+    int* ver;                                                  // (nt + mt) x nt tile versions (number of column steps applied)
     int* ctrl;                                                 // [0] ticket, [1] abort code, [3] arrival order, [8..8+DAG_TEAM) the team's CUs
     int* cnt;                                                  // per column step: strips published of the five team products
     double* pivots;                                            // the nt * 128 pivots d_j (their logarithms are summed by dag_finish_kernel)
@@ -196,6 +199,14 @@ __device__ __forceinline__ bool dag_wait(const DagArgs<T>& g, int ticket, const 
 }
 template <typename T>
 __device__ __forceinline__ const int* dag_ver(const DagArgs<T>& g, int i, int j) { return g.ver + (int64_t)i * g.nt + j; }
+// Tile row i: a block row of the factor (i < nt) or of the panel below it (the candidates' V^T, or the identity that
+// becomes L^-T); both are row-major with their own leading dimension.
+template <typename T>
+__device__ __forceinline__ T* dag_row(const DagArgs<T>& g, int i, int64_t& ldr) {
+    if (i < g.nt) { ldr = g.ld; return g.L + (int64_t)i * 128 * g.ld; }
+    ldr = g.ldp;
+    return g.P + (int64_t)(i - g.nt) * 128 * g.ldp;
+}
 // Publish tile (i, j) at version `ver`: every wave's (write-through) stores drained, barrier, version store.
 template <typename T>
 __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, int ver) {
@@ -220,7 +231,9 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
     const int lane = threadIdx.x & 63, fr = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    T* Cij = g.L + (int64_t)ti * 128 * g.ld + (int64_t)tj * 128;
+    int64_t ldr;
+    T* Ri = dag_row(g, ti, ldr);                               // tile row ti (factor or panel)
+    T* Cij = Ri + (int64_t)tj * 128;
     DAG_PHASE(ph0);
     acc_t acc[4][4];
     const T* A0;
@@ -235,9 +248,9 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][r] = -Cij[gi * g.ld + wc * 64 + j * 16 + fr];
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = -Cij[gi * ldr + wc * 64 + j * 16 + fr];
             }
-        A0 = g.L + (int64_t)ti * 128 * g.ld + (int64_t)k0 * 128;
+        A0 = Ri + (int64_t)k0 * 128;
         B0 = g.L + (int64_t)tj * 128 * g.ld + (int64_t)k0 * 128;
         ldb = g.ld;
         nkt = (k1 - k0) * (128 / (4 * F::EPC));
@@ -254,7 +267,7 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
         nkt = 128 / (4 * F::EPC);
     }
     DAG_PHASE(ph1);
-    tile_mainloop<T>(smem, A0, g.ld, B0, ldb, nkt, acc);
+    tile_mainloop<T>(smem, A0, ldr, B0, ldb, nkt, acc);
     DAG_PHASE(ph2);
     const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
@@ -263,7 +276,7 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * g.ld + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
+            for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * ldr + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
         }
 #ifdef ALGP_DAG_DEBUG
     // Where a K = 128 product spends its time (tools/dag_test.hip prints the means): "issuing" the 64 loads / 64 stores
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(s_ticket);
     __syncthreads();
-    if (role < DAG_TEAM) {
+    if (role < DAG_TEAM && !g.no_team) {
         if (tid == 0) __hip_atomic_store(&g.ctrl[8 + role], cu_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(3);
         if (role == 0) {
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(256) void dag_finish_kernel(const double* pivots, i
     if (threadIdx.x == 0) {
         double tot = 0;
         for (int t = 0; t < 256; ++t) tot += part[t];
-        *logdet_acc += tot;
+        if (logdet_acc) *logdet_acc += tot;
         if (ctrl[1] != 0) *info = -2147483647 - 1;             // stalled: reported as a HIP-level failure by the caller
     }
 }
@@ -585,13 +598,27 @@ struct DagSchedule {
     float makespan = 0;                                        // of the simulation, microseconds
 };
 
+// What the list covers besides the nt x nt factor: `mt` more tile rows below it (the "panel") that are carried along as
+// extra block rows of the factorisation -- TRSM / UPD tasks without a diagonal -- so that P <- P L^-T comes out of the
+// same launch.  mode 1: a dense panel (the candidates' B^T -> V^T, reference utils.py:300-301); mode 2: the identity
+// (mt == nt; tile row e is zero left of column e and stays so: only tiles (e, j >= e) exist) -> L^-T for the MLL
+// gradient (reference models.py:147-148).  solve_only: the factor is final already, the list holds the panel's tasks only.
+struct DagShape {
+    int nt = 0, mt = 0, mode = 0;
+    bool solve_only = false;
+    int pstart(int e) const { return mode == 2 ? e : 0; }      // first non-zero tile column of panel row e
+    bool operator==(const DagShape& o) const { return nt == o.nt && mt == o.mt && mode == o.mode && solve_only == o.solve_only; }
+};
+
 constexpr int DAG_FAR8 = 4, DAG_FAR16 = 16;                    // see the batches in dag_build_schedule
 static int batched_until(int j, int W) {                       // columns [0, kf) of tile column j arrive in batches of 4
     if (j < W) return 0;
     return 4 * ((j - W) / 4);
 }
 
-void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
+void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& out) {
+    const int nt = shape.nt, mt = shape.mt, R = nt + mt;
+    const bool solve_only = shape.solve_only;
     struct Node {
         DagTask t;
         float dur, prio;
@@ -601,7 +628,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
         std::vector<int> succ_start;                                        // nodes that may start once this one HAS STARTED
     };
     std::vector<Node> nodes;
-    std::vector<int> last_writer((size_t)nt * nt, -1), trsm((size_t)nt * nt, -1), diag(nt, -1);
+    std::vector<int> last_writer((size_t)R * nt, -1), trsm((size_t)R * nt, -1), diag(nt, -1);
     auto add = [&](int type, int i, int j, int k0, int k1, float dur) {
         Node n;
         n.t = DagTask{type, i, j, (k0 << 16) | k1};
@@ -640,36 +667,46 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             nodes[v].on_chain = true;
             return v;
         };
-        const int d = chain(k, k, D_DIAG);
-        edge(last_writer[(size_t)k * nt + k], d);
-        if (k + 1 < nt) {
-            const int h1 = chain(k + 1, k, D_STRIP);                         // TRSM(k+1,k)
-            edge(d, h1);
-            edge(prev_h5, h1);                                               // the helpers work in sequence
-            edge(last_writer[(size_t)(k + 1) * nt + k], h1);
-            trsm[(size_t)(k + 1) * nt + k] = h1;
-            const int h2 = chain(k + 1, k + 1, D_STRIP);                     // UPD(k+1,k+1,k)
-            edge(h1, h2);
-            edge(last_writer[(size_t)(k + 1) * nt + (k + 1)], h2);
-            last_writer[(size_t)(k + 1) * nt + (k + 1)] = h2;
-            prev_h5 = h2;
-            if (k + 2 < nt) {
-                const int h3 = chain(k + 2, k, D_STRIP);                     // TRSM(k+2,k)
-                edge(h2, h3);
-                edge(last_writer[(size_t)(k + 2) * nt + k], h3);
-                trsm[(size_t)(k + 2) * nt + k] = h3;
-                const int h4 = chain(k + 2, k + 1, D_STRIP);                 // UPD(k+2,k+1,k)
-                edge(h3, h4);
-                edge(last_writer[(size_t)(k + 2) * nt + (k + 1)], h4);
-                last_writer[(size_t)(k + 2) * nt + (k + 1)] = h4;
-                const int h5 = chain(k + 2, k + 2, D_STRIP);                 // UPD(k+2,k+2,k)
-                edge(h4, h5);
-                edge(last_writer[(size_t)(k + 2) * nt + (k + 2)], h5);
-                last_writer[(size_t)(k + 2) * nt + (k + 2)] = h5;
-                prev_h5 = h5;
+        int d = -1;
+        if (!solve_only) {
+            d = chain(k, k, D_DIAG);
+            edge(last_writer[(size_t)k * nt + k], d);
+            if (k + 1 < nt) {
+                const int h1 = chain(k + 1, k, D_STRIP);                         // TRSM(k+1,k)
+                edge(d, h1);
+                edge(prev_h5, h1);                                               // the helpers work in sequence
+                edge(last_writer[(size_t)(k + 1) * nt + k], h1);
+                trsm[(size_t)(k + 1) * nt + k] = h1;
+                const int h2 = chain(k + 1, k + 1, D_STRIP);                     // UPD(k+1,k+1,k)
+                edge(h1, h2);
+                edge(last_writer[(size_t)(k + 1) * nt + (k + 1)], h2);
+                last_writer[(size_t)(k + 1) * nt + (k + 1)] = h2;
+                prev_h5 = h2;
+                if (k + 2 < nt) {
+                    const int h3 = chain(k + 2, k, D_STRIP);                     // TRSM(k+2,k)
+                    edge(h2, h3);
+                    edge(last_writer[(size_t)(k + 2) * nt + k], h3);
+                    trsm[(size_t)(k + 2) * nt + k] = h3;
+                    const int h4 = chain(k + 2, k + 1, D_STRIP);                 // UPD(k+2,k+1,k)
+                    edge(h3, h4);
+                    edge(last_writer[(size_t)(k + 2) * nt + (k + 1)], h4);
+                    last_writer[(size_t)(k + 2) * nt + (k + 1)] = h4;
+                    const int h5 = chain(k + 2, k + 2, D_STRIP);                 // UPD(k+2,k+2,k)
+                    edge(h4, h5);
+                    edge(last_writer[(size_t)(k + 2) * nt + (k + 2)], h5);
+                    last_writer[(size_t)(k + 2) * nt + (k + 2)] = h5;
+                    prev_h5 = h5;
+                }
             }
         }
-        for (int i = k + 3; i < nt; ++i) {
+        auto row_task = [&](int i) {
+            if (k + 1 >= nt) {                                               // last column: nothing to update to its right
+                const int tr = add(DAG_TRSM, i, k, k, k + 1, D_OP + D_OVH);
+                edge(d, tr);
+                edge(last_writer[(size_t)i * nt + k], tr);
+                trsm[(size_t)i * nt + k] = tr;
+                return;
+            }
             // TRSM(i,k) and UPD(i,k+1,k) are one ticketed task (DAG_TU): in the simulation the ticketed node is the first
             // product (L_ik is published when it ends) and the second a continuation that starts when its other inputs
             // are there.  The ticket is handed out only after the second product's other input, the tile's last update,
@@ -688,7 +725,11 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             edge(last_writer[(size_t)i * nt + (k + 1)], u);
             edge(trsm[(size_t)(k + 1) * nt + k], u);
             last_writer[(size_t)i * nt + (k + 1)] = u;
-        }
+        };
+        if (!solve_only)
+            for (int i = k + 3; i < nt; ++i) row_task(i);
+        for (int e = 0; e < mt; ++e)                                         // panel rows: always ticketed, from their first column on
+            if (shape.pstart(e) <= k) row_task(nt + e);
         auto upd = [&](int i, int j, int k0, int k1) {
             const int u = add(DAG_UPD, i, j, k0, k1, D_OVH + D_OP * (k1 - k0));
             edge(last_writer[(size_t)i * nt + j], u);
@@ -698,12 +739,21 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
             }
             last_writer[(size_t)i * nt + j] = u;
         };
+        // rows that receive UPD(i, j, [k0, k1)): the factor's rows i >= j (the team's rows k+1, k+2 excepted for single
+        // steps) and every panel row that has started before k1 (its batch begins at its first column)
+        auto upd_rows = [&](int j, int k0, int k1, bool single) {
+            if (!solve_only)
+                for (int i = j; i < nt; ++i)
+                    if (!single || i > k + 2) upd(i, j, k0, k1);
+            for (int e = 0; e < mt; ++e) {
+                const int ps = shape.pstart(e);
+                if (ps < k1) upd(nt + e, j, std::max(k0, ps), k1);
+            }
+        };
         for (int j = k + 1; j < nt; ++j) {
             const int kf = batched_until(j, W);
             if (k >= kf) {
-                for (int i = j; i < nt; ++i)
-                    if (i > k + 2 && j != k + 1) upd(i, j, k, k + 1);   // single step (rows k+1, k+2 are the team's,
-                                                                             // column k+1 went with the TRSM: DAG_TU)
+                if (j != k + 1) upd_rows(j, k, k + 1, true);                 // single step (column k+1 went with the TRSM: DAG_TU)
             } else {
                 // Batches of four column steps (K = 512) next to the window, of eight (K = 1024) from DAG_FAR8 steps before
                 // it, of sixteen (K = 2048) from DAG_FAR16 steps before that: one read + write of the tile and one ticket /
@@ -713,13 +763,11 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
                 const int kf8 = std::max(0, 8 * ((kf - DAG_FAR8) / 8));      // [kf16, kf8) in eights, [kf8, kf) in fours
                 const int kf16 = std::max(0, 16 * ((kf8 - DAG_FAR16) / 16)); // [0, kf16) in sixteens
                 if (k < kf16) {
-                    if ((k + 1) % 16 == 0)
-                        for (int i = j; i < nt; ++i) upd(i, j, k - 15, k + 1);
+                    if ((k + 1) % 16 == 0) upd_rows(j, k - 15, k + 1, false);
                 } else if (k < kf8) {
-                    if ((k + 1) % 8 == 0)
-                        for (int i = j; i < nt; ++i) upd(i, j, k - 7, k + 1);
+                    if ((k + 1) % 8 == 0) upd_rows(j, k - 7, k + 1, false);
                 } else if ((k + 1) % 4 == 0) {
-                    for (int i = j; i < nt; ++i) upd(i, j, k - 3, k + 1);
+                    upd_rows(j, k - 3, k + 1, false);
                 }
             }
         }
@@ -765,7 +813,7 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
     out.tasks.clear();
     out.tasks.reserve(n);
     float now = 0;
-    int freew = workers - 2 * DAG_TEAM, started = 0;                         // the team and its retired CU neighbours
+    int freew = solve_only ? workers : workers - 2 * DAG_TEAM, started = 0;  // the team and its retired CU neighbours
     std::vector<int> just_started;
     auto release = [&](int v) {                                              // all inputs of v are there
         if (nodes[v].on_chain) {
@@ -842,44 +890,68 @@ void dag_build_schedule(int nt, int W, int workers, DagSchedule& out) {
 #endif
 }
 
+// One launch of the task list for `shape`: the factorisation of A (unless shape.solve_only) and, with a panel, P <- P L^-T
+// for the mt x 128 rows of P in the same launch.  The per-launch state (pivots | control words | team counters | tile
+// versions) is zeroed -- or, for lists whose tiles do not all start at version 0 (a final factor, identity rows that
+// begin at their own column), copied from a template kept beside the task list.
 template <typename T>
-int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
-    const int nt = (int)(npad / NB);
+static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* invD, T* P, int64_t ldp, double* logdet_acc,
+                      int* info) {
+    const int nt = shape.nt, mt = shape.mt, R = nt + mt;
     const int W = 2;     // fine (K=128) steps next to a tile's own column; >= 2: the team owns rows k+1, k+2.  With the K = 1024 / 2048
                          // batches of round 3: W = 2 / 3 / 4 / 6 -> 7.28 / 7.32 / 7.28 / 7.53 ms in fp64, 4.49 / 4.58 / 4.86 / 5.10 ms in fp32
+    const size_t nver = (size_t)R * nt;
+    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt) + sizeof(double) * 128 * nt + 16), 16);
+    const size_t ver_off = sizeof(double) * 128 * nt + sizeof(int) * ((DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt);
     DagCache* dc = nullptr;
     for (auto& e : c->dag_cache)
-        if (e.nt == nt) dc = &e;
+        if (e.nt == nt && e.mt == mt && e.mode == shape.mode && e.solve_only == (shape.solve_only ? 1 : 0)) dc = &e;
     if (!dc) {
         hipDeviceProp_t prop;
         ALGP_HIP(hipGetDeviceProperties(&prop, c->device));
         DagSchedule sched;
         const int workers = 2 * prop.multiProcessorCount;      // two workgroups per CU: the grid of the launch below
-        dag_build_schedule(nt, W, workers, sched);
-        if (c->dag_cache.size() >= 4) {                        // keep the four most recent sizes
+        dag_build_schedule(shape, W, workers, sched);
+        if (c->dag_cache.size() >= 6) {                        // keep the six most recent shapes
             ALGP_HIP(hipStreamSynchronize(c->cur));
-            hipFree(c->dag_cache.front().tasks.p);
-            c->dev_bytes -= (int64_t)c->dag_cache.front().tasks.cap;
+            for (DevBuf* b : {&c->dag_cache.front().tasks, &c->dag_cache.front().init})
+                if (b->p) { hipFree(b->p); c->dev_bytes -= (int64_t)b->cap; }
             c->dag_cache.erase(c->dag_cache.begin());
         }
         DagCache e;
         e.nt = nt;
+        e.mt = mt;
+        e.mode = shape.mode;
+        e.solve_only = shape.solve_only ? 1 : 0;
         e.workers = workers;
         e.ntasks = (int)sched.tasks.size();
-        ALGP_TRY(ensure(c, e.tasks, sizeof(DagTask) * sched.tasks.size()));
+        ALGP_TRY(ensure(c, e.tasks, sizeof(DagTask) * std::max<size_t>(sched.tasks.size(), 1)));
         ALGP_HIP(hipMemcpy(e.tasks.p, sched.tasks.data(), sizeof(DagTask) * sched.tasks.size(), hipMemcpyHostToDevice));
+        if (shape.solve_only || shape.mode == 2) {
+            std::vector<char> st(state_bytes, 0);
+            int* ver = (int*)(st.data() + ver_off);
+            if (shape.solve_only)                              // every tile of the factor is final
+                for (int i = 0; i < nt; ++i)
+                    for (int j = 0; j <= i; ++j) ver[(size_t)i * nt + j] = j + 1;
+            for (int r = 0; r < mt; ++r)                       // a panel row counts its column steps from its first column
+                for (int j = shape.pstart(r); j < nt; ++j) ver[(size_t)(nt + r) * nt + j] = shape.pstart(r);
+            int rc = ensure(c, e.init, state_bytes);
+            if (rc != ALGP_OK) { hipFree(e.tasks.p); c->dev_bytes -= (int64_t)e.tasks.cap; return rc; }
+            ALGP_HIP(hipMemcpy(e.init.p, st.data(), state_bytes, hipMemcpyHostToDevice));
+        }
         c->dag_cache.push_back(e);
         dc = &c->dag_cache.back();
     }
-    // per-launch state: tile versions, control words, per-block log-determinants (one zeroed block)
-    const size_t nver = (size_t)nt * nt;
-    const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt) + sizeof(double) * 128 * nt + 16), 16);
     ALGP_TRY(ensure(c, c->dag_state, state_bytes));
-    ALGP_HIP(hipMemsetAsync(c->dag_state.p, 0, state_bytes, c->cur));
+    if (dc->init.p) ALGP_HIP(hipMemcpyAsync(c->dag_state.p, dc->init.p, state_bytes, hipMemcpyDeviceToDevice, c->cur));
+    else ALGP_HIP(hipMemsetAsync(c->dag_state.p, 0, state_bytes, c->cur));
     DagArgs<T> g;
     g.L = A;
     g.ld = ld;
     g.invD = invD;
+    g.P = P;
+    g.ldp = ldp;
+    g.no_team = shape.solve_only ? 1 : 0;
     g.tasks = (const DagTask*)dc->tasks.p;
     g.ntasks = dc->ntasks;
     g.nt = nt;
@@ -903,24 +975,67 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
         }
         g.stats = (unsigned long long*)c->dag_stats.p;
     }
-    const double flops = (double)npad * npad * npad / 3.0;
+    const double npad = 128.0 * nt, mrows = 128.0 * mt;
+    // flop executed: N^3/3 for the factor, N^2 per dense panel row, N^3/3 in all for the identity panel
+    const double flops = (shape.solve_only ? 0.0 : npad * npad * npad / 3.0) +
+                         (shape.mode == 1 ? npad * npad * mrows : (shape.mode == 2 ? npad * npad * npad / 3.0 : 0.0));
     {
-        ProfScope ps(c, ALGP_PROF_CHOL_DAG, flops, sizeof(T) * (double)npad * npad);
+        ProfScope ps(c, mt > 0 ? ALGP_PROF_DAG_PANEL : ALGP_PROF_CHOL_DAG, flops, sizeof(T) * npad * (npad + mrows));
         int grid = dc->workers;                                // the machine the list schedule was simulated for
-        if (grid > dc->ntasks + DAG_TEAM) grid = dc->ntasks + DAG_TEAM;
+        const int team = shape.solve_only ? 0 : DAG_TEAM;
+        if (grid > dc->ntasks + team) grid = dc->ntasks + team;
+        if (grid < 1) grid = 1;
         hipLaunchKernelGGL(chol_dag_kernel<T>, dim3(grid), dim3(256), 0, c->cur, g);
         ALGP_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(dag_finish_kernel, dim3(1), dim3(256), 0, c->cur, g.pivots, 128 * nt, g.ctrl, logdet_acc, info);
+    // log-determinant from the pivots (factorising lists) and the abort word -> info
+    hipLaunchKernelGGL(dag_finish_kernel, dim3(1), dim3(256), 0, c->cur, g.pivots, shape.solve_only ? 0 : 128 * nt, g.ctrl, logdet_acc, info);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
+}
+
+template <typename T>
+int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
+    DagShape sh;
+    sh.nt = (int)(npad / NB);
+    return dag_launch<T>(c, sh, A, ld, invD, (T*)nullptr, 0, logdet_acc, info);
 }
 template int cholesky_dag<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*);
 template int cholesky_dag<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*);
 
+// The factorisation of A and P <- P L^-T in ONE launch: the mpad rows of P ride along as extra block rows of the task list
+// (mode 1: dense rows, the candidates' B^T -> V^T; mode 2: P = I, npad x npad -> L^-T, zero tiles never touched).
+template <typename T>
+int cholesky_dag_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info, T* P, int64_t ldp,
+                       int64_t mpad, int mode) {
+    DagShape sh;
+    sh.nt = (int)(npad / NB);
+    sh.mt = (int)(mpad / NB);
+    sh.mode = mode;
+    return dag_launch<T>(c, sh, A, ld, invD, P, ldp, logdet_acc, info);
+}
+template int cholesky_dag_panel<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*, double*, int64_t, int64_t, int);
+template int cholesky_dag_panel<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*, float*, int64_t, int64_t, int);
+
+// P <- P L^-T against a factor that is final (same task list without the factorisation's own tasks)
+template <typename T>
+int solve_dag_panel(algp_ctx* c, const T* L, int64_t npad, int64_t ld, const T* invD, int* info, T* P, int64_t ldp, int64_t mpad,
+                    int mode) {
+    DagShape sh;
+    sh.nt = (int)(npad / NB);
+    sh.mt = (int)(mpad / NB);
+    sh.mode = mode;
+    sh.solve_only = true;
+    return dag_launch<T>(c, sh, const_cast<T*>(L), ld, const_cast<T*>(invD), P, ldp, (double*)nullptr, info);
+}
+template int solve_dag_panel<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, int*, double*, int64_t, int64_t, int);
+template int solve_dag_panel<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, int*, float*, int64_t, int64_t, int);
+
 void dag_release(algp_ctx* c) {
-    for (auto& e : c->dag_cache)
+    for (auto& e : c->dag_cache) {
         if (e.tasks.p) hipFree(e.tasks.p);
+        if (e.init.p) hipFree(e.init.p);
+    }
     c->dag_cache.clear();
 }
 

@@ -15,6 +15,20 @@ constexpr double ENT_CONST = 1.4189385332046727;  // 1/2 log(2 pi e)  (reference
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// slots (doubles) of ctx->scal, the context's device scalars
+constexpr int SC_LOGDET = 0;
+constexpr int SC_INFO = 1;       // int stored in a double slot
+constexpr int SC_AUXLOGDET = 2;
+constexpr int SC_AUXINFO = 3;
+constexpr int SC_AMAXV = 4;
+constexpr int SC_AMAXI = 5;
+constexpr int SC_PROBE = 6;
+constexpr int SC_COMMIT = 8;     // (d_c, scale) of the pick being committed
+constexpr int SC_AMAXF = 10;     // fresh[argmax] of the lazy greedy
+constexpr int SC_STALL = 12;     // int, sticky: a one-launch kernel with inter-workgroup hand-offs gave up (sync_checked)
+constexpr int SC_GRAD = 16;      // 16..27: partial sums of the MLL gradient
+constexpr int SC_COUNT = 32;
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -45,7 +59,9 @@ struct PickRec {           // one committed greedy pick, host side (the device k
 
 struct DagCache {          // device copy of one task list of the dependency-driven Cholesky (chol_dag.hip)
     int64_t nt;
+    int mt = 0, mode = 0, solve_only = 0;   // the row panel carried below the factor (DagShape)
     DevBuf tasks;
+    DevBuf init;           // template of the per-launch state for lists whose tiles do not all start at version 0 (or null)
     int ntasks;
     int workers;           // workgroups the schedule was simulated for = the grid it is launched with
 };
@@ -270,6 +286,17 @@ void dag_release(algp_ctx* c);   // frees the cached task lists of the dependenc
 template <typename T>
 int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc,
                      int* info);
+// Sizes the one-launch task list (chol_dag.hip) serves: the factor's tile count, and the tile rows of a panel carried along
+constexpr int64_t DAG_MIN_TILES = 8, DAG_MAX_TILES = 192, DAG_MAX_PANEL_TILES = 320;
+bool dag_enabled();       // $ALGP_CHOL_DAG != 0
+// The factorisation and P <- P L^-T in one launch (P: mpad rows riding along as extra block rows of the task list;
+// mode 1: dense rows, mode 2: P = I of the factor's size -> L^-T); and the same solve against a factor that is final.
+template <typename T>
+int cholesky_dag_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info, T* P, int64_t ldp,
+                       int64_t mpad, int mode);
+template <typename T>
+int solve_dag_panel(algp_ctx* c, const T* L, int64_t npad, int64_t ld, const T* invD, int* info, T* P, int64_t ldp, int64_t mpad,
+                    int mode);
 // X (mpad x npad, ld ldx) <- X * L^-T, in place
 template <typename T>
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,

@@ -112,12 +112,16 @@ static int cholesky_serial(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD,
 template <typename T>
 int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info);
 
+// ALGP_CHOL_DAG=0 selects the launch sequences for every size (A/B runs, tests of the fallback)
+bool dag_enabled() {
+    static const int dag = getenv("ALGP_CHOL_DAG") ? atoi(getenv("ALGP_CHOL_DAG")) : 1;
+    return dag != 0;
+}
+
 template <typename T>
 int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info) {
-    // ALGP_CHOL_DAG=0 selects the launch sequence for every size (A/B runs, tests of the fallback)
-    static const int dag = getenv("ALGP_CHOL_DAG") ? atoi(getenv("ALGP_CHOL_DAG")) : 1;
     const int64_t nt = npad / NB;
-    if (dag && nt >= 8 && nt <= 192) return cholesky_dag<T>(c, A, npad, ld, invD, logdet_acc, info);
+    if (dag_enabled() && nt >= DAG_MIN_TILES && nt <= DAG_MAX_TILES) return cholesky_dag<T>(c, A, npad, ld, invD, logdet_acc, info);
     return cholesky_serial<T>(c, A, npad, ld, invD, logdet_acc, info);
 }
 template int cholesky_blocked<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*);

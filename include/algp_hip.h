@@ -61,7 +61,8 @@ enum {
     ALGP_PROF_GEMM_CHOL_UPDATE = 10, /* the Cholesky's K=512 trailing (rank-512) updates, a subset of GEMM_CHOL's work
                                       * counted here instead: the "dense panel update" of the blocked factorisation */
     ALGP_PROF_CHOL_DAG = 11,   /* the Cholesky as one dependency-driven launch (chol_dag.hip): the whole factorisation */
-    ALGP_PROF_COUNT = 12
+    ALGP_PROF_DAG_PANEL = 12,  /* the same launch carrying a row panel: factorisation + candidate solve (or + L^-T), or the solve alone */
+    ALGP_PROF_COUNT = 13
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

@@ -1,5 +1,6 @@
 """The ticket list of the one-launch Cholesky (chol_dag.hip: dag_build_schedule) replayed on the host, no GPU needed:
-for every matrix size the kernel serves (8 <= N/128 <= 192) and three residencies (512, 64 and 11 workgroups) the
+for every matrix size the kernel serves (8 <= N/128 <= 192), the window the library ships (W = 2) and three residencies
+(512, 64 and 11 workgroups) the
 list, executed strictly in ticket order by ONE bulk worker beside the chain team, finds every task's inputs already
 produced, applies every update exactly once in ascending k and completes the factorisation (tools/dag_sched_probe.hip
 restates the kernel's waits and publishes independently of the builder's graph).  A list that passes cannot deadlock at
@@ -19,4 +20,8 @@ def test_ticket_list_is_a_valid_sequential_order_for_every_size(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, '--check', '8', '192'], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and 'CHECK OK: 555 schedules' in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
+    assert r.returncode == 0 and 'CHECK OK: 555 schedules (N/128 = 8..192, W = 2)' in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
+    # lists that carry a row panel below the factor (the candidates' rows of algp_fit_and_solve, the identity that becomes
+    # L^-T), with and without the factorisation's own tasks: same replay, panel rows starting at their first column
+    r = subprocess.run([exe, '--check-panel', '8', '40'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'CHECK OK: 990 panel schedules' in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])

@@ -21,9 +21,21 @@ using namespace algp;
 // what the kernel's waits and publishes do to the tile versions, restated independently of dag_build_schedule's graph
 struct Replay {
     int nt;
+    DagShape sh;
     std::vector<int> ver;
     int lead_k = 0, help_k = 0, help_phase = 0;
-    explicit Replay(int n) : nt(n), ver((size_t)n * n, 0) {}
+    // the initial versions are what dag_launch's template holds: 0, a final factor for a solve-only list, and for a
+    // panel row its first column
+    explicit Replay(const DagShape& s) : nt(s.nt), sh(s), ver((size_t)(s.nt + s.mt) * s.nt, 0) {
+        if (s.solve_only) {
+            for (int i = 0; i < nt; ++i)
+                for (int j = 0; j <= i; ++j) v(i, j) = j + 1;
+            lead_k = nt;
+            help_k = nt;
+        }
+        for (int r = 0; r < s.mt; ++r)
+            for (int j = s.pstart(r); j < nt; ++j) v(nt + r, j) = s.pstart(r);
+    }
     int& v(int i, int j) { return ver[(size_t)i * nt + j]; }
     // the chain team advances as far as its inputs allow (leader: diagonal blocks; helpers: strips, in program order)
     void team() {
@@ -57,9 +69,12 @@ struct Replay {
             printf("nt %d ticket %d type %d (%d,%d) k %d..%d: %s\n", nt, ticket, t.type, i, j, k0, k1, why);
             return false;
         };
+        if (i >= nt + sh.mt || j >= nt) return bad("tile outside the matrix");
+        if (i >= nt && (j < sh.pstart(i - nt) || k0 < sh.pstart(i - nt))) return bad("a panel row touched left of its first column");
         if (t.type == DAG_TU) {
             // TRSM(i,k), then -- a wait in the middle of the task, the workgroup held -- UPD(i,k+1,k)
             const int k = j;
+            if (k + 1 >= nt) return bad("TU in the last column");
             if (v(i, k) != k) return bad("tile (i,k) is not at version k");
             if (v(k, k) < k + 1) return bad("diagonal block not factored");
             v(i, k) = k + 1;
@@ -85,36 +100,69 @@ struct Replay {
     }
 };
 
-static bool check(int nt, int W, int workers) {
+static bool check(const DagShape& sh, int W, int workers) {
+    const int nt = sh.nt;
     DagSchedule s;
-    dag_build_schedule(nt, W, workers, s);
-    Replay r(nt);
+    dag_build_schedule(sh, W, workers, s);
+    Replay r(sh);
     r.team();
     for (size_t t = 0; t < s.tasks.size(); ++t) {
         if (!r.run(s.tasks[t], (int)t)) return false;
         r.team();
     }
-    for (int i = 0; i < nt; ++i)
-        for (int j = 0; j <= i; ++j)
-            if (r.v(i, j) != j + 1) { printf("nt %d workers %d: tile (%d,%d) ends at version %d\n", nt, workers, i, j, r.v(i, j)); return false; }
+    for (int i = 0; i < nt + sh.mt; ++i)
+        for (int j = (i < nt ? 0 : sh.pstart(i - nt)); j <= (i < nt ? i : nt - 1); ++j)
+            if (r.v(i, j) != j + 1) {
+                printf("nt %d mt %d mode %d solve_only %d workers %d: tile (%d,%d) ends at version %d\n", nt, sh.mt, sh.mode, (int)sh.solve_only,
+                       workers, i, j, r.v(i, j));
+                return false;
+            }
     return true;
 }
 
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "--check")) {
-        const int lo = argc > 2 ? atoi(argv[2]) : 8, hi = argc > 3 ? atoi(argv[3]) : 192, W = argc > 4 ? atoi(argv[4]) : 4;
+        // W = 2 is what dag_launch ships
+        const int lo = argc > 2 ? atoi(argv[2]) : 8, hi = argc > 3 ? atoi(argv[3]) : 192, W = argc > 4 ? atoi(argv[4]) : 2;
         int n = 0;
         for (int nt = lo; nt <= hi; ++nt)
             for (int workers : {512, 64, 2 * DAG_TEAM + 1}) {
-                if (!check(nt, W, workers)) return 1;
+                DagShape sh;
+                sh.nt = nt;
+                if (!check(sh, W, workers)) return 1;
                 ++n;
             }
         printf("CHECK OK: %d schedules (N/128 = %d..%d, W = %d)\n", n, lo, hi, W);
         return 0;
     }
-    const int nt = argc > 1 ? atoi(argv[1]) : 79;
+    if (argc > 1 && !strcmp(argv[1], "--check-panel")) {
+        // lists that carry a row panel: dense rows (mode 1), the identity (mode 2), each with and without the factorisation
+        const int lo = argc > 2 ? atoi(argv[2]) : 8, hi = argc > 3 ? atoi(argv[3]) : 40, W = 2;
+        int n = 0;
+        for (int nt = lo; nt <= hi; ++nt)
+            for (int mode : {1, 2})
+                for (int so : {0, 1})
+                    for (int mt : {1, 3, nt, 2 * nt + 5}) {
+                        if (mode == 2 && mt != nt) continue;
+                        for (int workers : {512, 37, 2 * DAG_TEAM + 1}) {
+                            DagShape sh;
+                            sh.nt = nt; sh.mt = mt; sh.mode = mode; sh.solve_only = so != 0;
+                            if (!check(sh, W, workers)) return 1;
+                            ++n;
+                        }
+                    }
+        printf("CHECK OK: %d panel schedules (N/128 = %d..%d)\n", n, lo, hi);
+        return 0;
+    }
+    // dag_sched_probe NT [MT MODE SOLVE_ONLY]
+    DagShape sh;
+    sh.nt = argc > 1 ? atoi(argv[1]) : 79;
+    sh.mt = argc > 2 ? atoi(argv[2]) : 0;
+    sh.mode = argc > 3 ? atoi(argv[3]) : (sh.mt ? 1 : 0);
+    sh.solve_only = argc > 4 && atoi(argv[4]) != 0;
     DagSchedule s;
-    dag_build_schedule(nt, 4, 512, s);
-    printf("nt %d: %zu ticketed tasks, simulated makespan %.0f us\n", nt, s.tasks.size(), s.makespan);
+    dag_build_schedule(sh, 2, 512, s);
+    printf("nt %d mt %d mode %d solve_only %d: %zu ticketed tasks, simulated makespan %.0f us\n", sh.nt, sh.mt, sh.mode, (int)sh.solve_only,
+           s.tasks.size(), s.makespan);
     return 0;
 }
