@@ -92,6 +92,9 @@ SIGNATURES = {
     'algp_debug_fail_next_pick': (C.c_int, [_c_ctx, C.c_int]),
     'algp_debug_set_trsm_chunks': (C.c_int, [_c_ctx, C.c_int]),
     'algp_debug_dag_stall': (C.c_int, [_c_ctx, C.c_int]),
+    'algp_debug_trsv_stall': (C.c_int, [_c_ctx, C.c_int]),
+    'algp_debug_fail_at': (C.c_int, [_c_ctx, C.c_int, C.c_int]),
+    'algp_debug_get_pick': (C.c_int, [_c_ctx, C.c_int, C.c_void_p, C.c_int64, _i64p, _dblp]),
     'algp_debug_counter': (C.c_int64, [_c_ctx, C.c_int]),
     'algp_greedy_sharded': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_int, _i64p, _dblp]),
 }
@@ -440,6 +443,24 @@ class Context(object):
     def debug_dag_stall(self, ticket):
         """The next one-launch factorisation loses the publish of the task with this ticket (spin limit 0.2 s)."""
         self._check(self.lib.algp_debug_dag_stall(self.h, int(ticket)))
+
+    def debug_fail_at(self, where, code):
+        """Inject `code` into this rank's next greedy pick: where = 0 resolving its best, 1 committing the winner (after the
+        exchange), 2 packing its contribution (algp_debug_fail_at)."""
+        self._check(self.lib.algp_debug_fail_at(self.h, int(where), int(code)))
+
+    def debug_trsv_stall(self, block):
+        """The next one-launch forward / backward substitution loses the flag of this 128-block (spin limit 0.2 s)."""
+        self._check(self.lib.algp_debug_trsv_stall(self.h, int(block)))
+
+    def debug_get_pick(self, q):
+        """(row, d): pick q since the last solve as every rank committed it -- the winner's row of V^T (ncols values) and
+        its statistic; what the winner's owner contributes to the pick's all-gather (algp_debug_get_pick)."""
+        n, d = C.c_int64(), C.c_double()
+        self._check(self.lib.algp_debug_get_pick(self.h, int(q), None, 0, C.byref(n), C.byref(d)))
+        row = np.empty(n.value, dtype=self.dtype)
+        self._check(self.lib.algp_debug_get_pick(self.h, int(q), _ptr(row), len(row), C.byref(n), C.byref(d)))
+        return row, d.value
 
     def set_trsm_chunks(self, chunks):
         """Row-chunk streams of the candidate solve (1..4; 0 = default).  Same results for every setting."""

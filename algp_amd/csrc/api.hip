@@ -311,6 +311,7 @@ struct Impl {
             for (int64_t i = 0; i < N; ++i) c->train_var_host[i] = (double)((const T*)var)[i];
         c->train_dirty = true;       // the resident factor (if any) still describes fact_idx / fact_var
         c->solved = false;
+        if (c->comm || c->host_gather) ALGP_TRY(comm_reserve(c));   // the exchange's buffers follow the train set's size
         return ALGP_OK;
     }
 
@@ -552,7 +553,7 @@ struct Impl {
         c->alpha_valid = false;                   // alpha = L^-T z: on first use (need_alpha)
         std::vector<T> zh(Npad);
         ALGP_HIP(hipMemcpyAsync(zh.data(), c->z.p, sizeof(T) * Npad, hipMemcpyDeviceToHost, c->stream));
-        ALGP_TRY(sync(c));
+        ALGP_TRY(sync_checked(c, "factorize: forward substitution"));
         double q = 0;
         for (int64_t i = 0; i < N; ++i) q += (double)zh[i] * (double)zh[i];
         c->yalpha = q;    // y0' S^-1 y0 = |L^-1 y0|^2
@@ -895,7 +896,9 @@ struct Impl {
                                  (const int64_t*)c->Aidx.p, (const T*)c->alpha.p, c->hyp.kernel, (T)c->hyp.outputscale,
                                  (T)c->ybar, p(c->auxD)));
         ALGP_HIP(hipMemcpyAsync(mu_out, c->auxD.p, sizeof(T) * M, hipMemcpyDeviceToHost, c->stream));
-        return sync(c);
+        const int rc = sync_checked(c, "posterior_mean");
+        if (rc != ALGP_OK) c->alpha_valid = false;
+        return rc;
     }
 
     // ------------------------------------------------------------------ set entropies / inverse diagonals
@@ -1254,7 +1257,14 @@ struct Impl {
     // commit_enqueue: everything stream-ordered, nothing read back (the winner's statistic d_c and the scale of the
     // appended row stay on the device, in scal[SC_COMMIT..]); the local / remote decision is the host's, from the pool
     // index it already holds.
-    static int commit_enqueue(algp_ctx* c, int64_t pool_idx, double ss, double delta) {
+    // winner_payload (device, or null): the owner's contribution to the pick's all-gather (comm.hip) -- for a winner another
+    // rank owns, its statistic and its row of V^T are copied from there instead of being rebuilt from the factor.
+    static int commit_enqueue(algp_ctx* c, int64_t pool_idx, double ss, double delta, const char* winner_payload = nullptr) {
+        if (c->debug_fail_next_commit) {
+            const int code = c->debug_fail_next_commit;
+            c->debug_fail_next_commit = 0;
+            return fail(c, code, "commit_pick: failure injected by algp_debug_fail_at");
+        }
         if (!c->solved) return fail(c, ALGP_ERR_STATE, "commit_pick: call algp_solve_candidates first");
         if (pool_idx < 0 || pool_idx >= c->n_pool) return fail(c, ALGP_ERR_BAD_ARG, "commit_pick: index outside the pool");
         if ((int64_t)c->picks.size() >= MAX_APPEND) return fail(c, ALGP_ERR_STATE, "commit_pick: append capacity exhausted; re-factorize");
@@ -1270,6 +1280,11 @@ struct Impl {
             ALGP_HIP(hipMemsetAsync(c->lrow.p, 0, sizeof(T) * ldv, c->stream));
             ALGP_HIP(hipMemcpyAsync(c->lrow.p, p(c->Vt) + local * ldv, sizeof(T) * ncols, hipMemcpyDeviceToDevice, c->stream));
             dsrc = p(c->dstat) + local;
+        } else if (winner_payload) {
+            // the owner's row, bit for bit (it was current when it was packed: a stale best row asks for another round)
+            ALGP_HIP(hipMemsetAsync(c->lrow.p, 0, sizeof(T) * ldv, c->stream));
+            ALGP_HIP(hipMemcpyAsync(c->lrow.p, winner_payload + 32, sizeof(T) * ncols, hipMemcpyDeviceToDevice, c->stream));
+            dsrc = (const T*)(winner_payload + 24);
         } else {
             ALGP_TRY(remote_row(c, pool_idx, in_train));
             dsrc = remote_slots(c).dstat;
@@ -1296,7 +1311,14 @@ struct Impl {
         ALGP_TRY(commit_enqueue(c, pool_idx, ss, delta));
         double host[2];
         ALGP_HIP(hipMemcpyAsync(host, (double*)c->scal.p + SC_COMMIT, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        ALGP_TRY(sync(c));
+        const int src = sync_checked(c, "commit_pick");          // a remote row's forward substitution may have given up
+        if (src != ALGP_OK) {
+            c->picks.pop_back();
+            c->ncols -= 1;
+            c->lazy_stale = was_stale;
+            c->bounds_valid = false;
+            return src;
+        }
         const double scale = host[1];
         if (!(scale == scale) || isinf(scale)) {
             c->picks.pop_back();                                  // the rows never see the pick: its record is not counted
@@ -1401,6 +1423,7 @@ struct Impl {
         double* sc = (double*)c->scal.p;
         for (int pck = 0; pck < k; ++pck) {
             double rec[5];
+            const char* winner = nullptr;
             for (int round = 0;; ++round) {
                 int st = ALGP_OK;
                 if (c->debug_fail_next_pick) {
@@ -1411,16 +1434,27 @@ struct Impl {
                 } else if (!c->prior_noise) {
                     st = fail(c, ALGP_ERR_STATE, "greedy: candidates were set with predictive semantics");
                 }
+                if (st == ALGP_OK && c->pending_pick_error) {
+                    // the commit of an earlier winner failed on this rank after the exchange that chose it: reported here,
+                    // in the next gather this rank takes part in, so that every rank returns it from the same call
+                    st = fail(c, c->pending_pick_error, c->pending_pick_msg);
+                    c->pending_pick_error = 0;
+                }
                 if (st == ALGP_OK && c->M > 0) st = ensure_bounds(c, ALGP_CRIT_ENTROPY, static_std, mobile_std, ss, delta);
                 if (st == ALGP_OK && c->M > 0) st = enqueue_local_best(c, ss, delta);
                 const bool have = st == ALGP_OK && c->M > 0;             // an empty shard offers nothing; that is not an error
                 const std::string local_err = c->err;
                 ALGP_TRY(comm_pick_exchange(c, have ? sc + SC_AMAXV : nullptr, have ? (const int64_t*)(sc + SC_AMAXI) : nullptr,
                                             (const int64_t*)c->Cidx.p, c->lazy_stale ? (const int*)c->fresh.p : nullptr,
-                                            (int)c->picks.size(), st, rec));
+                                            (int)c->picks.size(), st, rec, &winner));
                 if (rec[3] >= 2.0) {
                     const int code = (int)rec[3];
                     if (st != ALGP_OK) return fail(c, st, local_err);
+                    if ((int)rec[4] == c->comm_rank || !(c->comm || c->host_gather)) {
+                        // this rank's own status word, raised on the device: the sticky stall word (sync_checked clears it)
+                        const int rc2 = sync_checked(c, "greedy");
+                        if (rc2 != ALGP_OK) return rc2;
+                    }
                     return fail(c, code, "greedy_sharded: rank " + std::to_string((int)rec[4]) + " failed with error " +
                                              std::to_string(code) + " while resolving its best candidate; no rank committed pick " +
                                              std::to_string(pck));
@@ -1435,7 +1469,16 @@ struct Impl {
             const int64_t pool_idx = (int64_t)rec[1];
             if (picks_out) picks_out[pck] = pool_idx;
             if (ut_out) ut_out[pck] = rec[0];
-            ALGP_TRY(commit_enqueue(c, pool_idx, ss, delta));
+            const int crc = commit_enqueue(c, pool_idx, ss, delta, winner);
+            if (crc != ALGP_OK) {
+                // after the exchange: the other ranks have committed.  With a collective still ahead in this call the failure
+                // travels in the next pick's status word (every rank then returns it); after the last pick it is returned here
+                // AND kept for the first gather of this rank's next call.
+                if (!(c->comm || c->host_gather)) return crc;             // one rank: nobody else to tell
+                c->pending_pick_error = crc;
+                c->pending_pick_msg = "greedy: committing pick " + std::to_string(pck) + " failed on this rank: " + c->err;
+                if (pck + 1 == k) return crc;
+            }
         }
         return ALGP_OK;
     }
@@ -1518,7 +1561,10 @@ struct Impl {
                                     (double*)c->auxW.p /* X = L^-T is spent: room for the per-workgroup partials */));
         double h[12];
         ALGP_HIP(hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-        ALGP_TRY(sync(c));
+        {
+            const int rc = sync_checked(c, "get_mll_grad");
+            if (rc != ALGP_OK) { c->alpha_valid = false; return rc; }
+        }
         for (int d = 0; d < D; ++d) grad_out[d] = 0.5 * h[2 + d];
         grad_out[D] = 0.5 * h[0];
         grad_out[D + 1] = 0.5 * c->hyp.noise * h[1];
@@ -1529,7 +1575,9 @@ struct Impl {
         if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_alpha: call algp_factorize first");
         ALGP_TRY(need_alpha(c));
         ALGP_HIP(hipMemcpyAsync(out, c->alpha.p, sizeof(T) * c->N, hipMemcpyDeviceToHost, c->stream));
-        return sync(c);
+        const int rc = sync_checked(c, "get_alpha");
+        if (rc != ALGP_OK) c->alpha_valid = false;
+        return rc;
     }
     static int get_factor(algp_ctx* c, void* out) {
         if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_factor: call algp_factorize first");
@@ -1862,6 +1910,28 @@ int algp_debug_set_trsm_chunks(algp_ctx* c, int chunks) {
     c->trsm_chunks = chunks;
     return ALGP_OK;
 }
+int algp_debug_trsv_stall(algp_ctx* c, int block) {
+    CHECK_CTX(c);
+    if (block < -1) return fail(c, ALGP_ERR_BAD_ARG, "debug_trsv_stall: a block >= 0, or -1 to disarm");
+    c->debug_trsv_stall_block = block;
+    return ALGP_OK;
+}
+int algp_debug_get_pick(algp_ctx* c, int q, void* row_out, int64_t row_capacity, int64_t* ncols_out, double* d_out) {
+    CHECK_CTX(c);
+    if (!c->solved || q < 0 || q >= (int)c->picks.size()) return fail(c, ALGP_ERR_BAD_ARG, "debug_get_pick: no such pick since the last solve");
+    LazyPick lp;
+    ALGP_HIP(hipMemcpyAsync(&lp, (const LazyPick*)c->lazypicks.p + q, sizeof(lp), hipMemcpyDeviceToHost, c->stream));
+    ALGP_HIP(hipStreamSynchronize(c->stream));
+    if (ncols_out) *ncols_out = lp.ncols;
+    if (d_out) *d_out = lp.d;
+    if (row_out) {
+        if (row_capacity < lp.ncols) return fail(c, ALGP_ERR_BAD_ARG, "debug_get_pick: row buffer too small");
+        ALGP_HIP(hipMemcpyAsync(row_out, (const char*)c->prevrows.p + (size_t)q * c->ldv * c->es, (size_t)lp.ncols * c->es,
+                                hipMemcpyDeviceToHost, c->stream));
+        ALGP_HIP(hipStreamSynchronize(c->stream));
+    }
+    return ALGP_OK;
+}
 int algp_debug_dag_stall(algp_ctx* c, int ticket) {
     CHECK_CTX(c);
     if (ticket < -1) return fail(c, ALGP_ERR_BAD_ARG, "debug_dag_stall: a ticket >= 0, or -1 to disarm");
@@ -1872,6 +1942,15 @@ int algp_debug_fail_next_pick(algp_ctx* c, int code) {
     CHECK_CTX(c);
     if (code != 0 && (code < 2 || code > ALGP_ERR_NO_DEVICE)) return fail(c, ALGP_ERR_BAD_ARG, "debug_fail_next_pick: an ALGP_ERR_* code >= 2, or 0");
     c->debug_fail_next_pick = code;
+    return ALGP_OK;
+}
+int algp_debug_fail_at(algp_ctx* c, int where, int code) {
+    CHECK_CTX(c);
+    if (code != 0 && (code < 2 || code > ALGP_ERR_NO_DEVICE)) return fail(c, ALGP_ERR_BAD_ARG, "debug_fail_at: an ALGP_ERR_* code >= 2, or 0");
+    if (where == 0) c->debug_fail_next_pick = code;
+    else if (where == 1) c->debug_fail_next_commit = code;
+    else if (where == 2) c->debug_fail_next_pack = code;
+    else return fail(c, ALGP_ERR_BAD_ARG, "debug_fail_at: where = 0 (pick), 1 (commit), 2 (pack)");
     return ALGP_OK;
 }
 int algp_comm_destroy(algp_ctx* c) {

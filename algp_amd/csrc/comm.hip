@@ -3,13 +3,14 @@
 // The reference's greedy loop (agent.py:313-354) evaluates every candidate independently given the factor of the
 // sampled set, so the candidate list shards over the GPUs of a node (one process per GPU, one algp_ctx each, the
 // factor replicated).  Per pick each rank resolves its own best candidate on the device (argmax -> refresh of the rows
-// whose bound can still win -> argmax, see api.hip) and contributes the 24-byte triple (utility, pool index, status) to
+// whose bound can still win -> argmax, see api.hip) and contributes (utility, pool index, status) + that candidate's
+// statistic and row of V^T (comm_payload_bytes: 32 B + one row, ~80 KB at N = 10 000 fp64) to
 // ONE all-gather on the context's stream; a one-thread kernel takes the first maximum in rank order (= np.argmax over
 // the concatenated scores, agent.py:349, shards being contiguous in rank order) and the worst status, and the 40-byte
 // result is the pick's ONLY read-back.  The status word is what keeps the ranks together: a rank that cannot score
 // (no solve, an allocation that failed, ...) still takes part in the gather and reports its error code there, so every
 // rank returns that error instead of waiting for a peer that left.  Every rank then commits the same winner to its shard
-// (a rank that does not own it rebuilds its row from the replicated factor on the device).
+// (a rank that does not own it copies the owner's row out of the gather buffer: no second collective, no rebuild).
 // Transports: RCCL (algp_comm_init; opened with dlopen, so the library loads and every single-GPU entry point works
 // without it), a caller-supplied host all-gather (algp_comm_init_host: MPI, gloo, ... -- also what lets two ranks share
 // ONE card in the tests, which RCCL refuses), or none (one rank: the same kernels without the gather).
@@ -86,23 +87,41 @@ static RcclApi* rccl_api(std::string* why) {
     return &api;
 }
 
-// triple[0] = the local best utility (-inf without a candidate), [1] = its pool index as a double (exact below 2^53;
-// -1: none), [2] = status: 0 fine | 1 the best row still lags behind the committed picks (its utility is only an upper
-// bound: one more refresh round) | >= 2 the ALGP_ERR_* code this rank failed with.  pos == null: no candidate.
+// What a rank contributes to the pick's all-gather, `comm_payload_bytes` per rank:
+//   double[0] = its best utility (-inf without a candidate), [1] = that candidate's pool index as a double (exact below
+//   2^53; -1: none), [2] = status: 0 fine | 1 the best row still lags behind the committed picks (its utility is only an
+//   upper bound: one more refresh round) | >= 2 the ALGP_ERR_* code this rank failed with;
+//   bytes 24..31: the candidate's statistic (pv or s) in the context's element type;
+//   bytes 32.. : its row of V^T (Npad + MAX_APPEND elements; zero beyond the active columns).
+// The row is what makes a remote commit a copy: every rank commits the winner by appending the winner's row to its own
+// shard (agent.py:352-354 with the candidates sharded) -- a rank that does not own the winner used to rebuild that row
+// from the replicated factor (a kernel row + a 0.42-ms forward substitution + three kernels per pick, on 7 of 8 ranks);
+// now it takes the owner's bits from the gather ($ALGP_GATHER_ROWS=0: the 32-byte header only, rows rebuilt).
 __global__ void pack_best_kernel(const double* val, const int64_t* pos, const int64_t* cidx, const int* fresh, int npicks,
-                                 int status, double* triple) {
+                                 int status, const int* sticky, double* triple) {
     const int64_t p = pos ? *pos : -1;
+    if (status == 0 && sticky && *sticky != 0) status = ALGP_ERR_HIP;     // a one-launch kernel of this rank gave up earlier
     triple[0] = p >= 0 ? *val : -INFINITY;
     triple[1] = p >= 0 ? (double)cidx[p] : -1.0;
     triple[2] = status != 0 ? (double)status : ((p >= 0 && fresh && fresh[p] < npicks) ? 1.0 : 0.0);
 }
+template <typename T>
+__global__ __launch_bounds__(256) void pack_row_kernel(const int64_t* pos, const T* Vt, int64_t ldv, int64_t ncols, int64_t rowlen,
+                                                       const T* dstat, char* payload) {
+    const int64_t p = pos ? *pos : -1;
+    T* row = (T*)(payload + 32);
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < rowlen) row[j] = (p >= 0 && j < ncols) ? Vt[p * ldv + j] : (T)0;
+    if (j == 0) *(T*)(payload + 24) = p >= 0 ? dstat[p] : (T)0;
+}
 // out = (utility, pool index, owning rank, status, first rank with a non-zero status): the first maximum in rank order
 // over the ranks that have a candidate -- a NaN utility never wins (the local argmax skips NaN as well), -inf does when
 // nothing else is on offer -- and the largest status word (error codes are >= 2, so they outrank "one more round")
-__global__ void first_max_kernel(const double* triples, int nranks, double* out) {
+__global__ void first_max_kernel(const char* payloads, int64_t stride, int nranks, double* out) {
     double bv = -INFINITY, bi = -1.0, br = -1.0, st = 0.0, bad = -1.0;
     for (int r = 0; r < nranks; ++r) {
-        const double v = triples[3 * r], i = triples[3 * r + 1], s = triples[3 * r + 2];
+        const double* t = (const double*)(payloads + (int64_t)r * stride);
+        const double v = t[0], i = t[1], s = t[2];
         if (s != 0.0) {
             if (bad < 0.0) bad = (double)r;
             if (!(s <= st)) st = s;                     // a NaN status counts as a failure too
@@ -147,6 +166,40 @@ int comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128) {
     c->host_gather = nullptr;
     c->comm_nranks = nranks;
     c->comm_rank = rank;
+    return comm_reserve(c);
+}
+
+static bool gather_rows_on() {
+    static const bool on = !(getenv("ALGP_GATHER_ROWS") && atoi(getenv("ALGP_GATHER_ROWS")) == 0);
+    return on;
+}
+// bytes a rank contributes per pick: the 32-byte header, and the row when rows travel (fixed by the train set's size, which
+// every rank shares -- the factor is replicated)
+size_t comm_payload_bytes(const algp_ctx* c) {
+    const bool multi = c->comm || c->host_gather;
+    if (!multi || !gather_rows_on()) return 32;
+    return 32 + (size_t)round_up((int64_t)((c->Npad + MAX_APPEND) * (int64_t)c->es), 16);
+}
+// Buffers of the exchange for the current train-set size: [own payload | nranks payloads | 5-double record] on the device,
+// pinned staging for the host transport.  Called when a communicator is attached and whenever the train set changes
+// (algp_set_train), so that no allocation is left for the middle of a pick.
+int comm_reserve(algp_ctx* c) {
+    const size_t pb = comm_payload_bytes(c);
+    const int nr = c->comm_nranks;
+    ALGP_TRY(ensure(c, c->commbuf, pb * (size_t)(nr + 1) + 5 * sizeof(double)));
+    if (c->host_gather) {
+        const size_t need = pb * (size_t)(nr + 1);
+        if (c->comm_host_cap < need) {
+            if (c->comm_host) hipHostFree(c->comm_host);
+            c->comm_host = nullptr;
+            c->comm_host_cap = 0;
+            if (hipHostMalloc(&c->comm_host, need, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, ALGP_ERR_OOM, "comm: hipHostMalloc(" + std::to_string(need) + ") for the host transport's staging failed");
+            }
+            c->comm_host_cap = need;
+        }
+    }
     return ALGP_OK;
 }
 
@@ -156,7 +209,7 @@ int comm_init_host(algp_ctx* c, int nranks, int rank, algp_allgather_fn fn, void
     c->host_gather_user = user;
     c->comm_nranks = nranks;
     c->comm_rank = rank;
-    return ALGP_OK;
+    return comm_reserve(c);
 }
 
 void comm_destroy(algp_ctx* c) {
@@ -164,6 +217,9 @@ void comm_destroy(algp_ctx* c) {
         RcclApi* api = rccl_api(nullptr);
         if (api) api->CommDestroy((ncclComm_t)c->comm);
     }
+    if (c->comm_host) hipHostFree(c->comm_host);
+    c->comm_host = nullptr;
+    c->comm_host_cap = 0;
     c->comm = nullptr;
     c->host_gather = nullptr;
     c->host_gather_user = nullptr;
@@ -173,58 +229,104 @@ void comm_destroy(algp_ctx* c) {
 
 // The exchange of one pick.  (val_dev, pos_dev): the local argmax as the kernels before left it on the device (null: this
 // rank has no candidate to offer); status: 0 or the ALGP_ERR_* code this rank failed with while preparing it.  Everything
-// is stream-ordered; the single synchronisation is the read-back of rec5 = (utility, pool index, owner, status, first
-// rank with a non-zero status), identical on every rank.  Returns non-zero only when the exchange ITSELF failed.
-int comm_pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev,
-                       const int* fresh_dev, int npicks, int status, double* rec5) {
+// is stream-ordered; the single synchronisation (RCCL transport; the host transport needs two more to stage the payloads
+// through host memory) is the read-back of rec5 = (utility, pool index, owner, status, first rank with a non-zero
+// status), identical on every rank.  *winner_payload: where the owner's payload sits in this rank's gather buffer (device).
+// No rank-local failure returns before the collective has been issued: a pack launch that fails turns into this rank's
+// status word (written from the host); only a failure of the transport itself (the collective call, the copies around the
+// caller's gather) returns early -- there is no exchange left to report it through.
+template <typename T>
+static int pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev, const int* fresh_dev,
+                         int npicks, int status, double* rec5, const char** winner_payload) {
     const int nr = c->comm_nranks;
-    ALGP_TRY(ensure(c, c->commbuf, sizeof(double) * (3 + 3 * (size_t)nr + 5)));
-    double* triple = (double*)c->commbuf.p;
-    double* all = triple + 3;
-    double* out = all + 3 * nr;
+    const bool multi = c->comm || c->host_gather;
+    const size_t pb = comm_payload_bytes(c);
+    const size_t need = pb * (size_t)(nr + 1) + 5 * sizeof(double);
+    if (!c->commbuf.p || c->commbuf.cap < need) {
+        // not reserved for this size (a train set that changed without algp_set_train, or a reservation that failed and was
+        // ignored): the one allocation that can still precede the collective
+        ALGP_TRY(comm_reserve(c));
+    }
+    char* own = (char*)c->commbuf.p;
+    char* all = own + pb;
+    double* out = (double*)(all + pb * (size_t)nr);
+    const int* sticky = (const int*)((const double*)c->scal.p + SC_STALL);
     hipLaunchKernelGGL(pack_best_kernel, dim3(1), dim3(1), 0, c->stream, val_dev, pos_dev, cidx_dev, fresh_dev, npicks, status,
-                       triple);
-    ALGP_HIP(hipGetLastError());
-    const double* gathered = all;
+                       sticky, (double*)own);
+    hipError_t pe = hipGetLastError();
+    if (pe == hipSuccess && pb > 32) {
+        const int64_t rowlen = (int64_t)(pb - 32) / (int64_t)sizeof(T);
+        const bool have_row = pos_dev && c->Vt.p && c->solved;
+        hipLaunchKernelGGL(pack_row_kernel<T>, dim3((unsigned)((rowlen + 255) / 256)), dim3(256), 0, c->stream,
+                           have_row ? pos_dev : (const int64_t*)nullptr, (const T*)c->Vt.p, c->ldv, c->ncols, rowlen,
+                           (const T*)c->dstat.p, own);
+        pe = hipGetLastError();
+    }
+    if (c->debug_fail_next_pack) {                              // algp_debug_fail_at(2): as if the pack launch had failed
+        pe = hipErrorLaunchFailure;
+        c->debug_fail_next_pack = 0;
+    }
+    if (pe != hipSuccess) {
+        // the launch failed: this rank still joins the gather, with the failure as its status word
+        const double t[4] = {-INFINITY, -1.0, (double)ALGP_ERR_HIP, 0.0};
+        c->err = std::string("greedy: packing the local best failed: ") + hipGetErrorString(pe);
+        (void)hipMemcpyAsync(own, t, sizeof(t), hipMemcpyHostToDevice, c->stream);
+        (void)hipStreamSynchronize(c->stream);                  // t is a stack array
+    }
+    const char* gathered = all;
     if (c->comm) {
         RcclApi* api = rccl_api(nullptr);
         if (!api) return fail(c, ALGP_ERR_STATE, "greedy_sharded: the RCCL communicator has no library behind it");
-        const ncclResult_t r = api->AllGather(triple, all, 3, ncclDouble, (ncclComm_t)c->comm, c->stream);
+        const ncclResult_t r = api->AllGather(own, all, pb, ncclChar, (ncclComm_t)c->comm, c->stream);
         if (r != ncclSuccess)
             return fail(c, ALGP_ERR_HIP, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(r) : "failed"));
     } else if (c->host_gather) {
-        // the caller's transport works on host memory: the triple goes down, the gathered triples come back up
-        std::vector<double> send(3), recv(3 * (size_t)nr);
-        ALGP_HIP(hipMemcpyAsync(send.data(), triple, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        // the caller's transport works on host memory: the payload goes down, the gathered payloads come back up
+        char* hs = (char*)c->comm_host;
+        char* hr = hs + pb;
+        ALGP_HIP(hipMemcpyAsync(hs, own, pb, hipMemcpyDeviceToHost, c->stream));
         ALGP_HIP(hipStreamSynchronize(c->stream));
         c->n_syncs++;
-        const int rc = c->host_gather(c->host_gather_user, send.data(), recv.data(), (int64_t)(3 * sizeof(double)));
+        const int rc = c->host_gather(c->host_gather_user, hs, hr, (int64_t)pb);
         if (rc != 0) return fail(c, ALGP_ERR_HIP, "greedy_sharded: the caller's all-gather returned " + std::to_string(rc));
-        ALGP_HIP(hipMemcpyAsync(all, recv.data(), 3 * sizeof(double) * nr, hipMemcpyHostToDevice, c->stream));
-        ALGP_HIP(hipStreamSynchronize(c->stream));       // recv goes out of scope
-        c->n_syncs++;
+        ALGP_HIP(hipMemcpyAsync(all, hr, pb * (size_t)nr, hipMemcpyHostToDevice, c->stream));
     } else {
-        gathered = triple;                               // one rank: the same reduction over its own triple
+        gathered = own;                                  // one rank: the same reduction over its own payload
     }
-    hipLaunchKernelGGL(first_max_kernel, dim3(1), dim3(1), 0, c->stream, gathered, c->comm || c->host_gather ? nr : 1, out);
+    hipLaunchKernelGGL(first_max_kernel, dim3(1), dim3(1), 0, c->stream, gathered, (int64_t)pb, multi ? nr : 1, out);
     ALGP_HIP(hipGetLastError());
     ALGP_HIP(hipMemcpyAsync(rec5, out, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     ALGP_HIP(hipStreamSynchronize(c->stream));
     c->n_syncs++;
+    if (winner_payload) {
+        const int owner = (int)rec5[2];
+        *winner_payload = (pb > 32 && owner >= 0 && owner < (multi ? nr : 1)) ? gathered + (size_t)owner * pb : nullptr;
+    }
     return ALGP_OK;
+}
+int comm_pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev,
+                       const int* fresh_dev, int npicks, int status, double* rec5, const char** winner_payload) {
+    return c->dtype == ALGP_F64 ? pick_exchange<double>(c, val_dev, pos_dev, cidx_dev, fresh_dev, npicks, status, rec5, winner_payload)
+                                : pick_exchange<float>(c, val_dev, pos_dev, cidx_dev, fresh_dev, npicks, status, rec5, winner_payload);
 }
 
 // test hook: first_max_kernel over a caller-made buffer of `nranks` triples (fabricated 8-rank cases on one GPU)
 int comm_debug_first_max(algp_ctx* c, const double* triples, int nranks, double* out5) {
-    ALGP_TRY(ensure(c, c->commbuf, sizeof(double) * (3 + 3 * (size_t)std::max(nranks, c->comm_nranks) + 5)));
-    double* all = (double*)c->commbuf.p + 3;
-    double* out = all + 3 * std::max(nranks, c->comm_nranks);
-    ALGP_HIP(hipMemcpyAsync(all, triples, 3 * sizeof(double) * nranks, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(first_max_kernel, dim3(1), dim3(1), 0, c->stream, all, nranks, out);
-    ALGP_HIP(hipGetLastError());
-    ALGP_HIP(hipMemcpyAsync(out5, out, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    ALGP_HIP(hipStreamSynchronize(c->stream));
-    return ALGP_OK;
+    DevBuf tmp;
+    ALGP_TRY(ensure(c, tmp, sizeof(double) * (3 * (size_t)nranks + 5)));
+    double* all = (double*)tmp.p;
+    double* out = all + 3 * nranks;
+    int rc = ALGP_OK;
+    if (hipMemcpyAsync(all, triples, 3 * sizeof(double) * nranks, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ALGP_ERR_HIP;
+    if (rc == ALGP_OK) {
+        hipLaunchKernelGGL(first_max_kernel, dim3(1), dim3(1), 0, c->stream, (const char*)all, (int64_t)(3 * sizeof(double)), nranks, out);
+        if (hipGetLastError() != hipSuccess) rc = ALGP_ERR_HIP;
+    }
+    if (rc == ALGP_OK && hipMemcpyAsync(out5, out, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ALGP_ERR_HIP;
+    hipStreamSynchronize(c->stream);
+    hipFree(tmp.p);
+    c->dev_bytes -= (int64_t)tmp.cap;
+    return rc == ALGP_OK ? ALGP_OK : fail(c, ALGP_ERR_HIP, "debug_first_max: HIP call failed");
 }
 
 }  // namespace algp

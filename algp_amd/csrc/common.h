@@ -71,6 +71,7 @@ struct LazyPick {          // device copy of a committed pick for the lazy greed
     int64_t ncols;         // columns of V^T the pick's dot product covers = the column its entry goes to
     double scale;
     int64_t in_train;
+    double d;              // the winner's statistic (pv or s) when it was committed: what `scale` was computed from
 };
 
 }  // namespace algp
@@ -174,10 +175,17 @@ struct algp_ctx {
     algp_allgather_fn host_gather = nullptr;
     void* host_gather_user = nullptr;
     int comm_nranks = 1, comm_rank = 0;
-    algp::DevBuf commbuf;    // [own triple | gathered triples | winner record]
+    algp::DevBuf commbuf;    // [own payload | gathered payloads | winner record], see comm.hip
+    void* comm_host = nullptr;           // pinned staging of the host transport: [own payload | gathered payloads]
+    size_t comm_host_cap = 0;
+    int pending_pick_error = 0;          // a commit that failed after an exchange: this rank's status word in its next pick
+    std::string pending_pick_msg;
     int64_t n_syncs = 0;     // stream synchronisations issued by the library (algp_debug_counter)
     int debug_dag_stall_ticket = -1; // algp_debug_dag_stall: the next one-launch factorisation loses this ticket's publish
+    int debug_trsv_stall_block = -1; // algp_debug_trsv_stall: the next one-launch substitution loses this block's flag
     int debug_fail_next_pick = 0;   // algp_debug_fail_next_pick: error code this rank reports in its next pick
+    int debug_fail_next_commit = 0; // algp_debug_fail_at(1): the next commit of a greedy pick fails with this code (after the exchange)
+    int debug_fail_next_pack = 0;   // algp_debug_fail_at(2): the next pick's pack launch counts as failed
 
     // scratch for auxiliary factorizations (entropy_from_cov, set entropies, MI terms, posterior cov)
     algp::DevBuf auxA, auxInv, auxW, auxIdx, auxVar, auxD, hostStage;
@@ -278,7 +286,9 @@ int comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128);
 void comm_destroy(algp_ctx* c);
 int comm_init_host(algp_ctx* c, int nranks, int rank, algp_allgather_fn fn, void* user);
 int comm_pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev,
-                       const int* fresh_dev, int npicks, int status, double* rec5);
+                       const int* fresh_dev, int npicks, int status, double* rec5, const char** winner_payload);
+int comm_reserve(algp_ctx* c);
+size_t comm_payload_bytes(const algp_ctx* c);
 int comm_debug_first_max(algp_ctx* c, const double* triples, int nranks, double* out5);
 void dag_release(algp_ctx* c);   // frees the cached task lists of the dependency-driven Cholesky
 // Cholesky of the npad x npad matrix A (ld), inverse diagonal blocks to invD (one dependency-driven launch, or the

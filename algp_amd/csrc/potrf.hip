@@ -416,44 +416,10 @@ template int syrk_skinny_sub<double>(algp_ctx*, int, const double*, int64_t, int
 template int syrk_skinny_sub<float>(algp_ctx*, int, const float*, int64_t, int64_t, int64_t, float*, int64_t, DevBuf&);
 
 // ---------------------------------------------------------------------------------------------
-// Vector solves (HBM-bound: each reads the lower triangle of L once).
-//   forward  b <- L^-1 b, right-looking: x_k = inv(L_kk) b_k ; b_{k+1:} -= L_{k+1:,k} x_k
-//   backward b <- L^-T b, right-looking: x_k = inv(L_kk)^T b_k ; b_{0:k} -= L_{k,0:k}^T x_k
+// Vector solves (HBM-bound: each reads the lower triangle of L once): forward b <- L^-1 b and backward b <- L^-T b,
+// each ONE launch of a workgroup per 128-block with flags between them (trsv_chain_kernel, trsv_chain_back_kernel), and the
+// start-up of a forward substitution that resumes at row k (tail_gemv2_kernel).
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool TRANS>
-__global__ __launch_bounds__(128) void diag_matvec_kernel(const T* inv, T* b) {
-    // x = inv * b (TRANS: inv^T * b) for one 128-block, in place
-    __shared__ T xb[128];
-    const int t = threadIdx.x;
-    xb[t] = b[t];
-    __syncthreads();
-    // the inverse block is lower triangular with explicit zeros above: walk all 128 terms so the
-    // loads are independent and can be issued in batches (a data-dependent trip count serialises them)
-    T s = (T)0;
-    if (!TRANS) {
-#pragma unroll 16
-        for (int k = 0; k < 128; ++k) s += inv[t * 128 + k] * xb[k];
-    } else {
-#pragma unroll 16
-        for (int k = 0; k < 128; ++k) s += inv[k * 128 + t] * xb[k];
-    }
-    b[t] = s;
-}
-
-// columns [0, ncol) of the row panel R (128 x ncol, ld): out[cidx] -= sum_r R[r][cidx] * x[r]
-template <typename T>
-__global__ __launch_bounds__(256) void panel_gemv_t_kernel(const T* R, int64_t ld, int64_t ncol, const T* x, T* out) {
-    __shared__ T xs[128];
-    if (threadIdx.x < 128) xs[threadIdx.x] = x[threadIdx.x];
-    __syncthreads();
-    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (col >= ncol) return;
-    T s = (T)0;
-#pragma unroll 8
-    for (int r = 0; r < 128; ++r) s += R[(int64_t)r * ld + col] * xs[r];
-    out[col] -= s;
-}
-
 // rows [k, k + nrows) of L against the solved leading part: uo[r] -= L[k+r][0:k] . u[0:k] (same for w), one
 // wave per row -- the start-up of a forward substitution that resumes at row k
 template <typename T>
@@ -508,9 +474,13 @@ template int tail_gemv2_launch<float>(algp_ctx*, const float*, int64_t, int64_t,
 // per block; the L segment of block j+1 is loaded while block j is multiplied and flag j+1 is awaited), then multiplies
 // by the inverse of its diagonal block and publishes z_i write-through.  512 threads: four per row, 32 columns each.
 // ---------------------------------------------------------------------------------------------
+// A wait that runs into its time limit (2 s; a lost hand-off) abandons the launch: the abort word ends every other wait, and
+// the context's sticky stall word (scal[SC_STALL]) tells the host at its next checked synchronisation -- or the next pick's
+// status word -- that what this launch was producing is incomplete (ALGP_ERR_HIP "stalled", as the task-list Cholesky).
+// skip_block: test hook (algp_debug_trsv_stall) -- that block's flag is never set.
 template <typename T, int NR>
 __global__ __launch_bounds__(512) void trsv_chain_kernel(const T* L, int64_t ld, const T* invD, T* b0, T* b1, int kb0, int nblk,
-                                                         int* ctrl) {
+                                                         int* ctrl, int* sticky, unsigned long long spin_limit, int skip_block) {
     __shared__ T zs[NR][128];
     __shared__ T red[NR][4][128];
     __shared__ int s_i, s_ok;
@@ -544,8 +514,9 @@ __global__ __launch_bounds__(512) void trsv_chain_kernel(const T* L, int64_t ld,
             for (unsigned spins = 0;; ++spins) {
                 if (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = true; break; }
                 if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {       // 2 s at 100 MHz
+                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > spin_limit) {       // 2 s at 100 MHz
                     atomicCAS(&ctrl[1], 0, i + 1);
+                    __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -598,20 +569,115 @@ __global__ __launch_bounds__(512) void trsv_chain_kernel(const T* L, int64_t ld,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&flags[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && i != skip_block) __hip_atomic_store(&flags[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Backward substitution b <- L^-T b as ONE launch (alpha = L^-T z of every posterior mean, algp_get_alpha and MLL gradient;
+// reference utils.py:301).  The mirror image of the kernel above: workgroup i (arrival ticket t -> block nblk-1-t, so the
+// blocks it waits for are held by workgroups that already run) walks DOWN column block i of L -- the tiles L_ji, j > i, as
+// the alpha_j appear -- accumulating sum_j L_ji^T alpha_j: thread (c, q) owns column c and the row quarter q of each tile
+// (for a fixed row the 128 threads of a quarter read 128 contiguous elements), the next tile is loaded while the current
+// one is multiplied and flag j-1 is awaited.  Then alpha_i = X_ii^T (z_i - sum), published write-through.
+// (The launch sequence this replaces was ~160 launches: 0.9 ms at N = 10 000.)
+template <typename T>
+__global__ __launch_bounds__(512) void trsv_chain_back_kernel(const T* L, int64_t ld, const T* invD, T* b, int nblk, int* ctrl,
+                                                              int* sticky, unsigned long long spin_limit, int skip_block) {
+    __shared__ T zs[128];
+    __shared__ T red[4][128];
+    __shared__ int s_i, s_ok;
+    const int tid = threadIdx.x, cc = tid & 127, q = tid >> 7;
+    if (tid == 0) s_i = nblk - 1 - atomicAdd(&ctrl[0], 1);
+    __syncthreads();
+    const int i = s_i;
+    if (i < 0) return;
+    int* flags = ctrl + 8;
+    T acc = (T)0;
+    const T* Lcol = L + (int64_t)(q * 32) * ld + (int64_t)i * 128 + cc;       // row 32 q of a tile in column block i
+    T cur[32], nxt[32];
+    if (i + 1 < nblk) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) cur[e] = Lcol[((int64_t)(nblk - 1) * 128 + e) * ld];
+    }
+    T xinv[32];                                                    // column cc of X_ii, rows 32 q ..: loaded long before they are needed
+    {
+        const T* X = invD + (int64_t)i * 128 * 128 + (int64_t)(q * 32) * 128 + cc;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) xinv[e] = X[e * 128];
+    }
+    for (int j = nblk - 1; j > i; --j) {
+        if (tid == 0) {
+            bool ok = false;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spins = 0;; ++spins) {
+                if (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = true; break; }
+                if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > spin_limit) {
+                    atomicCAS(&ctrl[1], 0, i + 1);
+                    __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_ok) return;                                         // wave-uniform: the launch is being abandoned
+        if (tid < 128) zs[tid] = __hip_atomic_load(b + (int64_t)j * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j - 1 > i) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) nxt[e] = Lcol[((int64_t)(j - 1) * 128 + e) * ld];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc += cur[e] * zs[q * 32 + e];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) cur[e] = nxt[e];
+        __syncthreads();                                           // zs is rewritten in the next round
+    }
+    red[q][cc] = acc;
+    __syncthreads();
+    if (tid < 128) zs[tid] = b[(int64_t)i * 128 + tid] - (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]);
+    __syncthreads();
+    {
+        T s = (T)0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) s += xinv[e] * zs[q * 32 + e];
+        red[q][cc] = s;
+    }
+    __syncthreads();
+    if (tid < 128) st_wt(b + (int64_t)i * 128 + tid, ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && i != skip_block) __hip_atomic_store(&flags[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// control words of a substitution launch (zeroed per launch) and the test hook's arguments
+static int trsv_prepare(algp_ctx* c, int nblk, unsigned long long* spin_limit, int* skip_block) {
+    const size_t bytes = sizeof(int) * (size_t)(nblk + 8);
+    ALGP_TRY(ensure(c, c->trsv_ctrl, bytes));
+    ALGP_HIP(hipMemsetAsync(c->trsv_ctrl.p, 0, bytes, c->cur));
+    *spin_limit = 200000000ull;                                    // 2 s at 100 MHz
+    *skip_block = -1;
+    if (c->debug_trsv_stall_block >= 0) {                          // algp_debug_trsv_stall: one launch with a lost flag
+        *skip_block = c->debug_trsv_stall_block;
+        *spin_limit = 20000000ull;                                 // 0.2 s
+        c->debug_trsv_stall_block = -1;
+    }
+    return ALGP_OK;
 }
 
 template <typename T>
 static int trsv_chain_launch(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b0, T* b1, int64_t kb_start) {
     const int nblk = (int)(npad / NB), kb0 = (int)kb_start;
     if (kb0 >= nblk) return ALGP_OK;
-    const size_t bytes = sizeof(int) * (size_t)(nblk + 8);
-    ALGP_TRY(ensure(c, c->trsv_ctrl, bytes));
-    ALGP_HIP(hipMemsetAsync(c->trsv_ctrl.p, 0, bytes, c->cur));
+    unsigned long long limit;
+    int skip;
+    ALGP_TRY(trsv_prepare(c, nblk, &limit, &skip));
+    int* sticky = (int*)((double*)c->scal.p + SC_STALL);
     const int nr = b1 ? 2 : 1;
     ProfScope ps(c, ALGP_PROF_TRSV, nr * (double)npad * npad, sizeof(T) * 0.5 * (double)npad * npad);
-    if (b1) hipLaunchKernelGGL((trsv_chain_kernel<T, 2>), dim3(nblk - kb0), dim3(512), 0, c->cur, L, ldl, invD, b0, b1, kb0, nblk, (int*)c->trsv_ctrl.p);
-    else hipLaunchKernelGGL((trsv_chain_kernel<T, 1>), dim3(nblk - kb0), dim3(512), 0, c->cur, L, ldl, invD, b0, (T*)nullptr, kb0, nblk, (int*)c->trsv_ctrl.p);
+    if (b1) hipLaunchKernelGGL((trsv_chain_kernel<T, 2>), dim3(nblk - kb0), dim3(512), 0, c->cur, L, ldl, invD, b0, b1, kb0, nblk, (int*)c->trsv_ctrl.p, sticky, limit, skip);
+    else hipLaunchKernelGGL((trsv_chain_kernel<T, 1>), dim3(nblk - kb0), dim3(512), 0, c->cur, L, ldl, invD, b0, (T*)nullptr, kb0, nblk, (int*)c->trsv_ctrl.p, sticky, limit, skip);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -629,17 +695,14 @@ template int trsv_forward2<double>(algp_ctx*, const double*, int64_t, int64_t, c
 template int trsv_forward2<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, float*, float*, int64_t);
 template <typename T>
 int trsv_backward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b) {
-    const int64_t nblk = npad / NB;
+    const int nblk = (int)(npad / NB);
+    if (nblk <= 0) return ALGP_OK;
+    unsigned long long limit;
+    int skip;
+    ALGP_TRY(trsv_prepare(c, nblk, &limit, &skip));
     ProfScope ps(c, ALGP_PROF_TRSV, (double)npad * npad, sizeof(T) * 0.5 * (double)npad * npad);
-    for (int64_t kb = nblk - 1; kb >= 0; --kb) {
-        hipLaunchKernelGGL((diag_matvec_kernel<T, true>), dim3(1), dim3(128), 0, c->cur, invD + kb * NB * NB,
-                           b + kb * NB);
-        const int64_t ncol = kb * NB;
-        if (ncol > 0) {
-            hipLaunchKernelGGL(panel_gemv_t_kernel<T>, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, c->cur,
-                               L + kb * NB * ldl, ldl, ncol, b + kb * NB, b);
-        }
-    }
+    hipLaunchKernelGGL(trsv_chain_back_kernel<T>, dim3(nblk), dim3(512), 0, c->cur, L, ldl, invD, b, nblk, (int*)c->trsv_ctrl.p,
+                       (int*)((double*)c->scal.p + SC_STALL), limit, skip);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

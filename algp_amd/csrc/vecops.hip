@@ -465,8 +465,11 @@ __global__ void commit_finalize_kernel(const T* dsrc, int in_train, double ss, d
     lp.ncols = ncols;
     lp.scale = scale;
     lp.in_train = in_train;
+    lp.d = dc;
     *lp_out = lp;
-    if (alive_local) {
+    // the winner retires -- unless its scale is not finite (a non-positive variance under the square root): the caller
+    // of algp_commit_pick then takes the pick back, and the site must stay selectable
+    if (alive_local && scale == scale && !isinf(scale)) {
         *alive_local = 0;
         *score_local = -INFINITY;
     }

@@ -238,6 +238,22 @@ int algp_greedy_sharded(algp_ctx* ctx, int criterion, double static_std, double 
  * algp_debug_dag_stall: in the next one-launch factorisation (chol_dag.hip) the task that draws `ticket` never publishes its
  * tile and the spin limit drops from 2 s to 0.2 s: its consumers run into the limit, the launch aborts itself and
  * algp_factorize returns ALGP_ERR_HIP ("stalled") -- the path a lost hand-off would take; the context stays usable. */
+/* algp_debug_trsv_stall: in the next one-launch forward or backward substitution (potrf.hip) the workgroup of 128-block
+ * `block` never sets its flag and the spin limit drops to 0.2 s: the launch abandons itself, the context's sticky stall
+ * word is set and the call that reads the result back (algp_factorize, algp_get_alpha, algp_commit_pick, the next pick of
+ * algp_greedy[_sharded]) returns ALGP_ERR_HIP ("stalled"); the context stays usable.
+ * algp_debug_get_pick: pick number q since the last candidate solve as every rank committed it: row_out = the winner's row
+ * of V^T (ncols_out elements, the context's dtype; ncols = Npad + q), d_out = its statistic when it was committed.  What a
+ * rank receives in the pick's all-gather from the winner's owner; bench.py uses it to fabricate the seven absent ranks of
+ * an eight-rank run on one GPU. */
+/* algp_debug_fail_at: inject `code` (an ALGP_ERR_* >= 2; 0 disarms) into this rank's next greedy pick at `where`:
+ * 0 = while resolving its best candidate (= algp_debug_fail_next_pick), 1 = in the commit of the winner, AFTER the exchange
+ * that chose it (the code travels in this rank's status word of its next pick: every rank returns it from that call; after
+ * the last pick of a call it is returned by this rank at once and reported again in its next call's first exchange),
+ * 2 = the launch that packs its contribution counts as failed (ALGP_ERR_HIP in its status word, the gather still runs). */
+int algp_debug_fail_at(algp_ctx* ctx, int where, int code);
+int algp_debug_trsv_stall(algp_ctx* ctx, int block);
+int algp_debug_get_pick(algp_ctx* ctx, int q, void* row_out, int64_t row_capacity, int64_t* ncols_out, double* d_out);
 int algp_debug_first_max(algp_ctx* ctx, const double* triples, int nranks, double out5[5]);
 int algp_debug_set_trsm_chunks(algp_ctx* ctx, int chunks);
 int algp_debug_fail_next_pick(algp_ctx* ctx, int code);

@@ -100,14 +100,15 @@ def test_one_host_round_trip_per_pick(ctx):
     got = ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)
     assert ctx.sync_count() - s0 == 6
     assert [int(p) for p in got] == [int(p) for p in want]
-    # the same chain through algp_greedy_sharded with a host transport of one rank: 1 record + 2 around the caller's gather
+    # the same chain through algp_greedy_sharded with a host transport of one rank: 1 record + 1 in front of the caller's
+    # gather (the payload has to be in host memory; the way back up is an asynchronous copy from pinned staging)
     ctx.comm_init_host(1, 0, lambda b: b)
     try:
         ctx.factorize()
         ctx.solve_candidates()
         s0 = ctx.sync_count()
         got2, gut = ctx.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
-        assert ctx.sync_count() - s0 == 3 * 6
+        assert ctx.sync_count() - s0 == 2 * 6
         assert [int(p) for p in got2] == [int(p) for p in want]
         for p in range(6):
             assert gut[p] == np.nanmax(ut[p])
@@ -163,7 +164,8 @@ want, ut = full.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
 want = [int(p) for p in want]
 full.close()
 
-# 1) balanced shards: same picks, same utilities, winners from both shards (remote commits on both ranks)
+# 1) balanced shards: same picks, same utilities, winners from both shards (remote commits on both ranks: the winner's
+#    row arrives in the gather, or -- ALGP_GATHER_ROWS=0 -- is rebuilt from the replicated factor)
 lo, hi = partition(len(cand), world)[rank]
 c = make(cand[lo:hi])
 c.comm_init_host(world, rank, gather)
@@ -171,10 +173,57 @@ for rep in range(2):
     c.factorize(); c.solve_candidates()
     got, gut = c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
     assert [int(p) for p in got] == want, (rank, got, want)
-    for p in range(6):          # not bit-equal: a shard of <= 4096 candidates is solved right-looking, the full list left-looking
+    for p in range(6):          # not bit-equal: a shard of <= 4096 candidates takes another solve order than the full list
         assert abs(gut[p] - np.nanmax(ut[p])) < 1e-11, (p, gut[p], np.nanmax(ut[p]))
 owners = [0 if int(np.where(cand == p)[0][0]) < partition(len(cand), world)[0][1] else 1 for p in want]
 assert len(set(owners)) == 2, owners
+# the state after the six commits: every row of this shard has received every pick -- its utilities are those of the
+# one-rank run after the same six picks (remote rows copied from the gather are the owner's bits)
+ref = make(cand)
+ref.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)
+uref = ref.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)[lo:hi]
+ush = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+fin = np.isfinite(uref)
+assert np.array_equal(fin, np.isfinite(ush)) and np.max(np.abs(uref[fin] - ush[fin])) < 1e-11
+ref.close()
+
+# 1b) a commit that fails on ONE rank after the exchange: with a pick still ahead in the call, BOTH ranks return the error
+#     from that call (it travels in the failing rank's next status word) ...
+c.factorize(); c.solve_candidates()
+if rank == 1:
+    c.debug_fail_at(1, _hip.ERR_OOM)
+try:
+    c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)
+    raise SystemExit('rank %%d: the failed commit was lost' %% rank)
+except MemoryError as e:
+    assert ('rank 1' in str(e)) or rank == 1, str(e)
+#     ... and after the LAST pick of a call the failing rank returns it at once and reports it again in the first exchange
+#     of its next call, where every rank sees it
+c.factorize(); c.solve_candidates()
+if rank == 1:
+    c.debug_fail_at(1, _hip.ERR_OOM)
+try:
+    c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 1)
+    assert rank == 0
+except MemoryError:
+    assert rank == 1
+try:
+    c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 2)
+    raise SystemExit('rank %%d: the pending commit failure was not reported in the next call' %% rank)
+except MemoryError:
+    pass
+# 1c) the launch that packs a rank's contribution fails: its status word says so, the gather still runs, both ranks return
+c.factorize(); c.solve_candidates()
+if rank == 0:
+    c.debug_fail_at(2, _hip.ERR_HIP)
+try:
+    c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 2)
+    raise SystemExit('rank %%d: the failed pack was lost' %% rank)
+except _hip.AlgpError as e:
+    assert e.code == _hip.ERR_HIP
+c.factorize(); c.solve_candidates()
+got = c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)
+assert [int(p) for p in got] == want, (rank, got, want)
 
 # 2) one rank fails while resolving its pick: BOTH ranks return that error, nobody hangs, nobody committed
 c.factorize(); c.solve_candidates()
@@ -212,12 +261,20 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_through_the_abi_collective(tmp_path):
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize('rows_in_gather', ['1', '0'], ids=['rows-travel', 'rows-rebuilt'])
+def test_two_ranks_through_the_abi_collective(tmp_path, rows_in_gather):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'repo': REPO})
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', ALGP_GATHER_ROWS=rows_in_gather)
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29573', str(script)],
+                          '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'SHARDED_ABI_OK' in out.stdout
