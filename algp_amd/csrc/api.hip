@@ -731,7 +731,7 @@ struct Impl {
     // candidates on 4-8 GPUs, a held-out set) runs as ONE task-list launch (chol_dag.hip without the factorisation's
     // own tasks; $ALGP_SOLVE_DAG=0: the launch sequences of potrf.hip); everything else is trsm_blocked.
     static int solve_run(algp_ctx* c, const SolvePlan& pl) {
-        static const bool solve_dag_on = !(getenv("ALGP_SOLVE_DAG") && atoi(getenv("ALGP_SOLVE_DAG")) == 0);
+        const bool solve_dag_on = !(getenv("ALGP_SOLVE_DAG") && atoi(getenv("ALGP_SOLVE_DAG")) == 0);   // read per call: tests flip it
         const int64_t Npad = c->Npad, Mpad = c->Mpad, ldc = c->ldv, keep = pl.keep;
         prof_span_begin(c, ALGP_PROF_TRSM, (double)(Npad - keep) * (double)(Npad + keep) * (double)Mpad,
                         sizeof(T) * (double)Mpad * (double)Npad);
@@ -814,7 +814,7 @@ struct Impl {
     // the factorisation, then the three-stream sweep of potrf.hip, which wins from ~40 000 rows on.  (Overlapping the two
     // as separate launch sequences on streams was measured in round 1 -- 207 vs 193 ms/step -- and removed.)
     static int fit_and_solve(algp_ctx* c) {
-        static const bool fold_on = !(getenv("ALGP_FOLD") && atoi(getenv("ALGP_FOLD")) == 0);
+        const bool fold_on = !(getenv("ALGP_FOLD") && atoi(getenv("ALGP_FOLD")) == 0);                  // read per call: tests flip it
         if (!fold_on || c->M == 0 || !panel_fits(c->Npad, c->Mpad)) {
             ALGP_TRY(factorize(c, 0));
             return solve_candidates(c, 0, nullptr);

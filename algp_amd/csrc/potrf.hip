@@ -169,7 +169,9 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
         //   helper: wait a[J] . P(J) . record b[J]                            P = push into everything beyond the next block
         // Every column block receives its pushes in ascending J (P(J-1) before Q(J), both before I(J+1)).
         constexpr int64_t PW = WB;                                  // (1024-wide pushes: 25.2 ms at 12 500 rows, 41.9 at 25 000)
-        hipStream_t sa = c->cur, sb = (c->cur == c->stream && c->stream2) ? c->stream2 : nullptr;
+        // ($ALGP_TRSM_PUSH_STREAMS=1: everything on the caller's stream -- the same arithmetic, for the cross-check in the tests)
+        const bool one_stream = getenv("ALGP_TRSM_PUSH_STREAMS") && atoi(getenv("ALGP_TRSM_PUSH_STREAMS")) == 1;
+        hipStream_t sa = c->cur, sb = (!one_stream && c->cur == c->stream && c->stream2) ? c->stream2 : nullptr;
         int rc = ALGP_OK;
         int64_t jb = 0;
         for (int64_t j0 = 0; j0 < npad && rc == ALGP_OK; j0 += PW, ++jb) {

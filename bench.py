@@ -324,6 +324,129 @@ def sources_sha16():
     return h.hexdigest()[:16]
 
 
+def strong_emulation(ctx, _hip, res, args):
+    """What ONE rank of a 2 / 4 / 8-rank strong-scaling run of config 4 does, measured on this GPU through the product
+    path itself: the same train set, the rank's contiguous share of the candidates, algp_fit_and_solve, then
+    algp_greedy_sharded over algp_comm_init_host(n, r, fn) -- pack -> gather -> first maximum -> commit, remote commits
+    included.  `fn` stands in for the n - 1 absent ranks: the global winners, their utilities, statistics and rows of V^T
+    are known from the one-rank run (picks are identical by construction, and that run holds every candidate's row), so it
+    answers (-inf, -1, 0) for every absent rank except the winner's owner, whose true contribution it supplies.  Timed for
+    the first and the last rank of each n.  Left out: the wire time of RCCL's all-gather (n x 80 KB per pick) and skew
+    between ranks; the host transport used here costs two stream synchronisations and ~0.7 MB of PCIe traffic per pick
+    instead, plus the Python callback."""
+    import struct
+    from algp_amd.sharded import partition
+    w0, N0, total = res['w'], res['N'], res['total_c']
+    k = args.picks
+    allc = np.arange(N0, N0 + total)
+    out = {'by_gpus': {}}
+    try:
+        # the one-rank run once more, keeping what the absent owners would send: utility, statistic and row per pick
+        ctx.set_candidates(allc, prior_includes_noise=True)
+        ctx.fit_and_solve()
+        picks, ut = ctx.greedy(_hip.CRIT_ENTROPY, w0['static_std'], w0['mobile_std'], k, want_utilities=True)
+        picks = [int(p) for p in picks]
+        util = [float(np.nanmax(ut[q])) for q in range(k)]
+        del ut
+        rows = [ctx.debug_get_pick(q) for q in range(k)]
+        if picks != [int(p) for p in res['picks']]:
+            raise RuntimeError('the picks of the reference run changed: %s vs %s' % (picks, res['picks']))
+        # the replicated fit on its own (what every rank repeats): median of 5
+        ts = []
+        for _ in range(6):
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.factorize()
+            ctx.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        fit_alone = float(np.median(ts[1:]))
+        out['fit_alone_ms'] = fit_alone
+        es = ctx.dtype.itemsize
+        for n in (2, 4, 8):
+            parts = partition(total, n)
+            per_rank = {}
+            for r in sorted(set((0, n - 1))):
+                lo, hi = parts[r]
+                share = allc[lo:hi]
+                owners = [next(s for s, (a, b) in enumerate(parts) if a <= (p - N0) < b) for p in picks]
+                state = {'q': 0, 'pb': None, 'tmpl': None, 'calls': 0}
+
+                def build(pb):
+                    absent = struct.pack('<4d', float('-inf'), -1.0, 0.0, 0.0)
+                    tm = []
+                    for q in range(k):
+                        buf = bytearray(n * pb)
+                        for s_ in range(n):
+                            buf[s_ * pb:s_ * pb + 32] = absent
+                        if owners[q] != r:
+                            row, d = rows[q]
+                            o = owners[q] * pb
+                            buf[o:o + 24] = struct.pack('<3d', util[q], float(picks[q]), 0.0)
+                            buf[o + 24:o + 24 + es] = np.asarray([d], dtype=ctx.dtype).tobytes()
+                            rb = row.tobytes()
+                            buf[o + 32:o + 32 + len(rb)] = rb
+                        tm.append(buf)
+                    return tm
+
+                def fn(send, r=r, state=state, build=build):
+                    pb = len(send)
+                    if state['pb'] != pb:
+                        state['pb'], state['tmpl'] = pb, build(pb)
+                    state['calls'] += 1
+                    q = min(state['q'], k - 1)
+                    buf = state['tmpl'][q]
+                    buf[r * pb:(r + 1) * pb] = send
+                    if struct.unpack_from('<d', send, 16)[0] == 0.0:     # a settled round: the next call is the next pick
+                        state['q'] += 1
+                    return bytes(buf)
+
+                ctx.set_candidates(share, prior_includes_noise=True)
+                ctx.comm_init_host(n, r, fn)
+                try:
+                    def one():
+                        state['q'] = 0
+                        ctx.fit_and_solve()
+                        return ctx.greedy_sharded(_hip.CRIT_ENTROPY, w0['static_std'], w0['mobile_std'], k)
+                    got = [int(p) for p in one()]
+                    if got != picks:
+                        raise RuntimeError('rank %d of %d picked %s, the one-rank run %s' % (r, n, got, picks))
+                    ctx.prof_enable(True)
+                    ctx.prof_reset()
+                    ctx.sync()
+                    reps = 4
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        one()
+                    ctx.sync()
+                    ms = (time.perf_counter() - t0) / reps * 1e3
+                    pr = {kk: ctx.prof_get(kk) for kk in ('cholesky', 'trsm', 'dag_panel')}
+                    ctx.prof_enable(False)
+                finally:
+                    ctx.comm_destroy()
+                folded = pr['dag_panel']['launches'] > 0 and pr['trsm']['launches'] == 0
+                fs_ms = (pr['dag_panel']['ms'] if folded else pr['cholesky']['ms'] + pr['trsm']['ms']) / reps
+                fl = float(N0) ** 3 / 3.0 + float(N0) ** 2 * len(share)
+                per_rank[str(r)] = {
+                    'candidates': int(len(share)), 'ms_per_step_with_remote_commits': ms,
+                    'remote_commits_per_step': int(sum(1 for o in owners if o != r)),
+                    'fit_and_solve_ms': fs_ms, 'fit_and_solve_in_one_launch': bool(folded),
+                    'fit_and_solve_tflops': fl / (fs_ms * 1e-3) / 1e12 if fs_ms > 0 else None,
+                    'exchanges_per_step': state['calls'] / float(reps + 1)}
+            worst = max(v['ms_per_step_with_remote_commits'] for v in per_rank.values())
+            out['by_gpus'][str(n)] = {'ranks': per_rank, 'ms_per_step': worst}
+    except Exception as e:
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        print('bench: strong-scaling emulation failed: %s' % e, file=sys.stderr)
+        return None
+    finally:
+        try:
+            ctx.set_candidates(allc, prior_includes_noise=True)
+        except Exception:
+            pass
+    return out
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` launched plainly: start the N ranks as a CHILD `python -m torch.distributed.run`
     (never an exec, and before this process has imported torch or touched HIP), relay rank 0's JSON line, exit with the
@@ -534,38 +657,7 @@ def main():
 
     emu = None
     if rank == 0 and world == 1 and want != 'weak' and not args.no_emulation:
-        # What ONE rank of a 2 / 4 / 8-rank strong-scaling run does, measured on this GPU: the same train set, its share of the
-        # candidates (the first 1/n of the list), the same picks loop without the all-gather.  Every rank of such a run does
-        # this much work; what the emulation leaves out is the exchange (24 bytes per rank and pick), the commit of winners
-        # that another rank owns (one forward substitution each) and skew between ranks.
-        emu = {}
-        try:
-            w0, N0 = res['w'], res['N']
-            allc = np.arange(N0, N0 + res['total_c'])
-            for n in (2, 4, 8):
-                share = allc[:len(allc) // n]
-                ctx.set_candidates(share, prior_includes_noise=True)
-
-                def one():
-                    ctx.fit_and_solve()
-                    ctx.greedy(_hip.CRIT_ENTROPY, w0['static_std'], w0['mobile_std'], args.picks)
-                one()
-                ctx.prof_enable(True)
-                ctx.prof_reset()
-                ctx.sync()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    one()
-                ctx.sync()
-                ms = (time.perf_counter() - t0) / 3 * 1e3
-                fit = ctx.prof_get('cholesky')['ms'] / 3
-                tr = ctx.prof_get('trsm')['ms'] / 3
-                ctx.prof_enable(False)
-                emu[str(n)] = {'candidates_per_rank': int(len(share)), 'ms_per_step': ms, 'fit_ms': fit, 'trsm_ms': tr,
-                               'trsm_tflops': float(N0) ** 2 * len(share) / (tr * 1e-3) / 1e12 if tr > 0 else None}
-        except Exception as e:
-            print('bench: strong-scaling emulation failed: %s' % e, file=sys.stderr)
-            emu = None
+        emu = strong_emulation(ctx, _hip, res, args)
 
     if rank == 0:
         K = args.steps
@@ -673,13 +765,20 @@ def main():
                                                 '-- optimistic: a solve of 1/n of the candidates runs at a lower rate, see strong_emulation',
                                         'by_gpus': proj}
             if emu:
-                for n, e in emu.items():
+                for n, e in emu['by_gpus'].items():
                     e['speedup_vs_1'] = ms_step / e['ms_per_step']
-                    e['scoring_only_ms'] = max(e['ms_per_step'] - e['fit_ms'], 0.0)
+                    e['scoring_only_ms'] = max(e['ms_per_step'] - emu['fit_alone_ms'], 0.0)
                     e['scoring_only_speedup_vs_1'] = sharded_ms / e['scoring_only_ms'] if e['scoring_only_ms'] > 0 else None
-                out['strong_emulation'] = {'note': 'MEASURED on this one GPU: the step of one rank of an n-rank strong-scaling run (same '
-                                                   'train set, 1/n of the candidates, same picks loop, no all-gather, no remote commits); '
-                                                   'an upper bound of what n GPUs can reach, not a multi-GPU measurement', 'by_gpus': emu}
+                emu['note'] = ('MEASURED on this one GPU through algp_fit_and_solve + algp_greedy_sharded over algp_comm_init_host(n, r, fn): the step '
+                               'of the first and of the last rank of an n-rank strong-scaling run (same train set, the rank\'s 1/n of the '
+                               'candidates, pack -> gather -> first maximum -> commit with the REMOTE commits of winners other ranks own); fn '
+                               'fabricates the absent ranks\' contributions from the one-rank run (the true utility, statistic and row of '
+                               'each winner).  ms_per_step = the slower of the two ranks; speedup_vs_1 = this run\'s ms_per_step / that; '
+                               'scoring_only_* subtract the replicated fit timed on its own (fit_alone_ms) from the rank\'s step and '
+                               'stage_ms_per_step.cholesky from the one-GPU step.  Not in it: RCCL\'s wire time for n x 80 KB per pick (the '
+                               'host transport\'s two synchronisations, PCIe copies and Python callback are in it instead) and skew between '
+                               'ranks.  Up to 40 960 rows the fit and the solve are ONE task-list launch (fit_and_solve_in_one_launch).')
+                out['strong_emulation'] = emu
         if weak is not None:
             out['weak_scaling'] = {'value': weak['total_c'] / (weak['elapsed'] / K), 'unit': 'candidates/s',
                                    'ms_per_step': 1e3 * weak['elapsed'] / K,
