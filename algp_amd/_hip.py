@@ -56,6 +56,7 @@ SIGNATURES = {
     'algp_get_factor': (C.c_int, [_c_ctx, C.c_void_p]),
     'algp_get_mll': (C.c_int, [_c_ctx, _dblp]),
     'algp_get_mll_grad': (C.c_int, [_c_ctx, _dblp]),
+    'algp_fit_step': (C.c_int, [_c_ctx, _dblp, _dblp]),
     'algp_set_candidates': (C.c_int, [_c_ctx, _i64p, C.c_int64, C.c_int, C.c_void_p]),
     'algp_solve_candidates': (C.c_int, [_c_ctx]),
     'algp_solve_candidates_update': (C.c_int, [_c_ctx, C.c_void_p, _i64p]),
@@ -291,6 +292,14 @@ class Context(object):
         g = np.empty(self.D + 2, dtype=np.float64)
         self._check(self.lib.algp_get_mll_grad(self.h, g.ctypes.data_as(_dblp)))
         return g
+
+    def fit_step(self):
+        """(mll, grad): factorisation, marginal log likelihood and its gradient for the current hyper-parameters in one
+        call -- the device work of one iteration of GPR.fit (algp_fit_step)."""
+        g = np.empty(self.D + 2, dtype=np.float64)
+        v = C.c_double()
+        self._check(self.lib.algp_fit_step(self.h, C.byref(v), g.ctypes.data_as(_dblp)))
+        return v.value, g
 
     def alpha(self):
         out = np.empty(self.N, dtype=self.dtype)

@@ -322,6 +322,8 @@ struct Impl {
         int64_t ldp, mpad;
         int mode;                  // 1: dense rows (the candidates' B^T), 2: the identity (-> L^-T)
         bool done;
+        T* inv_out = nullptr;      // mode 2: S^-1 = P P^T (lower tiles, ld = mpad) is enqueued on the helper stream right behind
+        bool inv_enqueued = false; // the launch, beside the substitutions and read-backs that follow on the main stream
     };
     static bool panel_fits(int64_t npad, int64_t mpad) {
         const int64_t nt = npad / NB, mt = mpad / NB;
@@ -338,6 +340,17 @@ struct Impl {
             ALGP_TRY(cholesky_dag_panel<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info), panel->P, panel->ldp,
                                            panel->mpad, panel->mode));
             panel->done = true;
+            if (panel->mode == 2 && panel->inv_out && c->stream2 && c->cur == c->stream) {
+                hipEvent_t ready = sync_event_api(c, 20), done = sync_event_api(c, 21);
+                ALGP_HIP(hipEventRecord(ready, c->stream));
+                ALGP_HIP(hipStreamWaitEvent(c->stream2, ready, 0));
+                c->cur = c->stream2;
+                const int rc = syrk_upper<T>(c, ALGP_PROF_GEMM_OTHER, panel->P, panel->mpad, panel->ldp, panel->inv_out, panel->mpad);
+                c->cur = c->stream;
+                ALGP_HIP(hipEventRecord(done, c->stream2));
+                ALGP_TRY(rc);
+                panel->inv_enqueued = true;
+            }
         } else {
             ALGP_TRY(cholesky_blocked<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info)));
         }
@@ -1542,19 +1555,24 @@ struct Impl {
         return sync(c);
     }
 
-    static int mll_grad(algp_ctx* c, double* grad_out) {
+    // have_X: c->auxW already holds X = L^-T (it rode along with the factorisation as an identity panel); inv_enqueued: and
+    // S^-1 = X X^T is already running on the helper stream (event 21 marks its end)
+    static int mll_grad(algp_ctx* c, double* grad_out, bool have_X = false, bool inv_enqueued = false) {
         if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_mll_grad: call algp_factorize first");
         if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "get_mll_grad needs a coordinate pool");
         const int64_t N = c->N, Npad = c->Npad;
         const int D = c->hyp.D, DP = c->hyp.DP;
         ALGP_TRY(need_alpha(c));
-        ALGP_TRY(ensure(c, c->auxW, sizeof(T) * Npad * Npad));
         ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Npad * Npad));
         // X = I L^-T = L^-T ;  S^-1 = X X^T (lower tiles)
-        ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), Npad, Npad));
-        ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), c->Lld, p(c->invD)));
-        ALGP_TRY(syrk_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->auxA), Npad));
-        double* sc = (double*)c->scal.p + 16;             // slots 16..27: os, trace, ls[0..8)
+        if (!have_X) {
+            ALGP_TRY(ensure(c, c->auxW, sizeof(T) * Npad * Npad));
+            ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), Npad, Npad));
+            ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), c->Lld, p(c->invD)));
+        }
+        if (inv_enqueued) ALGP_HIP(hipStreamWaitEvent(c->stream, sync_event_api(c, 21), 0));
+        else ALGP_TRY(syrk_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->auxA), Npad));
+        double* sc = (double*)c->scal.p + SC_GRAD;        // slots 16..27: os, trace, ls[0..8)
         ALGP_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 12, c->stream));
         ALGP_TRY(mll_grad_launch<T>(c, p(c->auxA), Npad, N, (const T*)c->Xs.p, DP, (const int64_t*)c->Aidx.p,
                                     (const T*)c->alpha.p, c->hyp.kernel, (T)c->hyp.outputscale, sc,
@@ -1569,6 +1587,36 @@ struct Impl {
         grad_out[D] = 0.5 * h[0];
         grad_out[D + 1] = 0.5 * c->hyp.noise * h[1];
         return ALGP_OK;
+    }
+
+    // f2: the device work of ONE iteration of GPR.fit (models.py:145-158: loss = -mll(model(train_x), train_y); backward) in
+    // one ABI call: S, its factor AND X = L^-T out of the same task-list launch (the identity rides along as a panel
+    // whose zero tiles are never touched), alpha by the two one-launch substitutions, S^-1 = X X^T as one
+    // triangular-aware launch, the pairwise gradient reduction.  Same values as algp_factorize + algp_get_mll +
+    // algp_get_mll_grad (tested); N^3 flop in all (N^3/3 each for the factor, the inverse of the factor and the product).
+    static int fit_step(algp_ctx* c, double* mll_out, double* grad_out) {
+        if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "fit_step needs a coordinate pool");
+        const int64_t Npad = c->Npad;
+        bool have_X = false, inv_enq = false;
+        if (c->N > 0 && panel_fits(Npad, Npad)) {
+            ALGP_TRY(ensure(c, c->auxW, sizeof(T) * Npad * Npad));
+            ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Npad * Npad));
+            ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), Npad, Npad));
+            Panel pn{p(c->auxW), Npad, Npad, 2, false};
+            pn.inv_out = grad_out ? p(c->auxA) : nullptr;
+            const int frc = factorize(c, 0, &pn);
+            if (pn.inv_enqueued && (frc != ALGP_OK || !grad_out)) hipStreamSynchronize(c->stream2);   // nothing outlives the call
+            ALGP_TRY(frc);
+            have_X = pn.done;
+            inv_enq = pn.inv_enqueued;
+        } else {
+            ALGP_TRY(factorize(c, 0));
+        }
+        if (mll_out) *mll_out = -0.5 * c->yalpha - 0.5 * c->logdet - 0.5 * (double)c->N * 1.8378770664093453;
+        if (!grad_out) return ALGP_OK;
+        const int grc = mll_grad(c, grad_out, have_X, inv_enq);
+        if (grc != ALGP_OK && inv_enq) hipStreamSynchronize(c->stream2);
+        return grc;
     }
 
     static int get_alpha(algp_ctx* c, void* out) {
@@ -1786,6 +1834,13 @@ int algp_get_mll_grad(algp_ctx* c, double* grad) {
     CHECK_CTX(c);
     if (!grad) return fail(c, ALGP_ERR_BAD_ARG, "get_mll_grad: bad arguments");
     FINISH(c, DISPATCH(c, mll_grad(c, grad)));
+}
+int algp_fit_step(algp_ctx* c, double* mll, double* grad) {
+    CHECK_CTX(c);
+    NEED_HYPERS(c);
+    if (c->n_pool <= 0) return fail(c, ALGP_ERR_STATE, "fit_step: set a pool first");
+    if (!c->y0.p || (int64_t)c->pos_in_train.size() != c->n_pool) return fail(c, ALGP_ERR_STATE, "fit_step: call algp_set_train first");
+    FINISH(c, DISPATCH(c, fit_step(c, mll, grad)));
 }
 int algp_get_alpha(algp_ctx* c, void* out) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_alpha(c, out))); }
 int algp_get_factor(algp_ctx* c, void* out) { CHECK_CTX(c); FINISH(c, DISPATCH(c, get_factor(c, out))); }

@@ -268,7 +268,7 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
 template <typename T>
 int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
                            int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
-                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch);
+                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri = 0);
 // C (m x m, lower tiles) -= X X^T for a short, very wide X (m <= 512 rows, k columns): the k range is cut into
 // chunks that run as one batched launch, the partial products are summed in chunk order (deterministic)
 template <typename T>
@@ -317,6 +317,7 @@ int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T
 // C (lower tiles, npad x npad) <- X X^T for that upper-triangular X
 template <typename T>
 int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T* C, int64_t ldc);
+
 // b <- L^-1 b (forward) and b <- L^-T b (backward) for one vector of length npad
 template <typename T>
 int trsv_forward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* invD, T* b, int64_t kb_start = 0);

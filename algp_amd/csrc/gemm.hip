@@ -29,6 +29,7 @@
 //   workgroup then reads exactly the rows it later overwrites and finishes reading first.
 #include "common.h"
 #include "mfma.h"
+#include <algorithm>
 
 namespace algp {
 
@@ -43,6 +44,8 @@ struct GemmArgs {
     int tiles_m, tiles_n, ktiles;
     T alpha, beta;
     int lower_only;
+    int ktri;                      // lower_only products of an UPPER-triangular operand with itself (X X^T, X = L^-T): row tile bm of
+                                   // X is zero left of column 128 bm, so tile (bm, bn <= bm) sums over k >= 128 bm only
 };
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -68,22 +71,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
     __shared__ __attribute__((aligned(1024))) char smem[NST * 16384];
 
     const int nwg = gridDim.x;
-    int sid;
-    {
-        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
-        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    }
     int bm, bn;
-    if (g.lower_only) {
-        bm = (int)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= sid) ++bm;
-        while ((int64_t)bm * (bm + 1) / 2 > sid) --bm;
-        bn = sid - (int)((int64_t)bm * (bm + 1) / 2);
+    if (g.ktri) {
+        // Tile row bm costs (bm + 1) tiles x K = k - 128 bm: a contiguous share of the tile list per XCD (below) would give the
+        // XCD with the first rows several times the work of the last.  Instead XCD x takes the tile rows bm = x, x + 8, ...
+        // (its rows' tiles share the row panel of X through its L2), longest K first; the grid holds 8 x the largest share
+        // and the surplus workgroups of the other XCDs leave at once.
+        int local = blockIdx.x >> 3;
+        bm = blockIdx.x & 7;
+        while (bm < g.tiles_m && local > bm) { local -= bm + 1; bm += 8; }
+        if (bm >= g.tiles_m) return;
+        bn = local;
     } else {
-        bm = sid / g.tiles_n;
-        bn = sid - bm * g.tiles_n;
+        int sid;
+        {
+            const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+            sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        }
+        if (g.lower_only) {
+            bm = (int)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
+            while ((int64_t)(bm + 1) * (bm + 2) / 2 <= sid) ++bm;
+            while ((int64_t)bm * (bm + 1) / 2 > sid) --bm;
+            bn = sid - (int)((int64_t)bm * (bm + 1) / 2);
+        } else {
+            bm = sid / g.tiles_n;
+            bn = sid - bm * g.tiles_n;
+        }
     }
     const int64_t m0 = (int64_t)bm * 128, n0 = (int64_t)bn * 128;
+    const int kskip = g.ktri ? bm * (128 / (4 * MF<T>::EPC)) : 0;   // 64-byte k-tiles this output tile leaves out
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -93,8 +109,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
     // the group, LDS slot l&3, which must hold chunk (l&3) ^ ((row>>2)&3) = (l&3) ^ ((l>>4)&3)
     const int srow = lane >> 2;
     const int schunk = (lane & 3) ^ ((lane >> 4) & 3);
-    const T* Ag = g.A + bz * g.sA + (m0 + 32 * wave + srow) * g.lda + schunk * EPC;
-    const T* Bg = g.B + bz * g.sB + (n0 + 32 * wave + srow) * g.ldb + schunk * EPC;
+    const T* Ag = g.A + bz * g.sA + (m0 + 32 * wave + srow) * g.lda + schunk * EPC + (int64_t)kskip * BK;
+    const T* Bg = g.B + bz * g.sB + (n0 + 32 * wave + srow) * g.ldb + schunk * EPC + (int64_t)kskip * BK;
     auto stage = [&](int st, int kt) {
         char* As = smem + st * 16384 + wave * 2048;
         char* Bs = As + 8192;
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
-    const int nkt = g.ktiles * 2;                                  // g.ktiles counts 128-byte tiles
+    const int nkt = g.ktiles * 2 - kskip;                          // g.ktiles counts 128-byte tiles
     // prologue: tiles 0 .. NST-2 in flight
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
 template <typename T>
 int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
                            int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
-                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch) {
+                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri) {
     if (m <= 0 || n <= 0 || batch <= 0) return ALGP_OK;
     if (m % 128 || n % 128 || k % 128 || k <= 0 || lda % 4 || ldb % 4 || sA % 4 || sB % 4)
         return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: operands must be padded to multiples of 128");
@@ -214,13 +230,28 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
     g.ktiles = (int)(k / (8 * MF<T>::EPC));
     g.alpha = alpha; g.beta = beta;
     g.lower_only = lower_only;
+    g.ktri = ktri;
+    if (ktri && (!lower_only || k != m)) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: ktri needs a square lower-only product with k == m");
     const int64_t tiles = lower_only ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffff) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: grid too large");
-    const double flops = 2.0 * 128.0 * 128.0 * (double)k * (double)tiles * batch;
+    // ktri: tile row bm holds bm + 1 tiles of K = k - 128 bm: sum_bm (bm + 1)(tm - bm) = tm (tm + 1)(tm + 2) / 6 tile-steps of 128
+    const double tm = (double)g.tiles_m;
+    const double flops = ktri ? 2.0 * 128.0 * 128.0 * 128.0 * tm * (tm + 1.0) * (tm + 2.0) / 6.0 * batch
+                              : 2.0 * 128.0 * 128.0 * (double)k * (double)tiles * batch;
     const double bytes = sizeof(T) * batch * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
                                               (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     ProfScope ps(c, klass, flops, bytes);
-    const dim3 grid((unsigned)tiles, (unsigned)batch);
+    int64_t gx = tiles;
+    if (ktri) {                                                    // 8 x the largest per-XCD share (rows x, x + 8, ... of XCD x)
+        int64_t most = 0;
+        for (int x = 0; x < 8; ++x) {
+            int64_t cnt = 0;
+            for (int64_t r = x; r < g.tiles_m; r += 8) cnt += r + 1;
+            most = std::max(most, cnt);
+        }
+        gx = 8 * most;
+    }
+    const dim3 grid((unsigned)gx, (unsigned)batch);
     hipLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
@@ -231,7 +262,7 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
                    int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
                    int64_t ldd, int lower_only) {
     return gemm_nt_launch_batched<T>(c, klass, m, n, k, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, D, ldd, 0,
-                                     lower_only, 1);
+                                     lower_only, 1, 0);
 }
 
 template int gemm_nt_launch<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
@@ -240,10 +271,10 @@ template int gemm_nt_launch<float>(algp_ctx*, int, int64_t, int64_t, int64_t, fl
                                    const float*, int64_t, float, const float*, int64_t, float*, int64_t, int);
 template int gemm_nt_launch_batched<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
                                             int64_t, const double*, int64_t, int64_t, double, const double*, int64_t,
-                                            int64_t, double*, int64_t, int64_t, int, int);
+                                            int64_t, double*, int64_t, int64_t, int, int, int);
 template int gemm_nt_launch_batched<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
                                            int64_t, const float*, int64_t, int64_t, float, const float*, int64_t, int64_t,
-                                           float*, int64_t, int64_t, int, int);
+                                           float*, int64_t, int64_t, int, int, int);
 
 // ---------------------------------------------------------------------------------------------
 // MFMA fragment-layout probe (exact integer data, asymmetric B).

@@ -260,12 +260,15 @@ int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T
     return ALGP_OK;
 }
 
-// C (lower tiles) <- X X^T for the upper-triangular X above, as a sum over 512-wide column panels of X:
-// panel kp is zero below row kp + 512, so it only touches the leading (kp+512)^2 corner.  Descending kp,
-// so that the first (full-size) launch initialises every tile.  K = 512 panels stay L2/MALL-resident;
-// one GEMM with K = N streams X from HBM once per tile row (measured 28 TFLOP/s at N = 9000).
+// C (lower tiles) <- X X^T for the upper-triangular X above: ONE launch in which output tile (a, b <= a) sums over the
+// columns k >= 128 a only (row tile a of X is zero left of them; GemmArgs::ktri).  The tiles are dealt out by ascending a,
+// i.e. longest K first, so the 512 resident workgroups end within one short tile of each other.  (Rounds 1-3: a sum over
+// 512-wide column panels of X, 20 launches whose first few hold fewer tiles than the machine has slots; $ALGP_SYRK_PANELS=1.)
 template <typename T>
 int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T* C, int64_t ldc) {
+    const bool panels = getenv("ALGP_SYRK_PANELS") && atoi(getenv("ALGP_SYRK_PANELS")) == 1;
+    if (!panels)
+        return gemm_nt_launch_batched<T>(c, klass, npad, npad, npad, (T)1, X, ldx, 0, X, ldx, 0, (T)0, nullptr, ldc, 0, C, ldc, 0, 1, 1, 1);
     const int64_t last = (npad - 1) / WB * WB;
     for (int64_t kp = last; kp >= 0; kp -= WB) {
         const int64_t w = (npad - kp < WB) ? npad - kp : WB, m = kp + w;

@@ -167,9 +167,9 @@ class GPR(object):
         c = self.ctx
         if self.sync_hypers():
             pass
-        c.factorize()
+        mll, grad = c.fit_step()             # factorisation + MLL + gradient: one ABI call per Adam iteration
         n = max(1, len(self._train_y))
-        return -c.mll() / n, -c.mll_grad() / n
+        return -mll / n, -grad / n
 
     def fit(self, x, y, var=None, disp=False):
         if var is None:

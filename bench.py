@@ -315,6 +315,51 @@ def extra_mi(_hip, device):
     return out
 
 
+def extra_fit(_hip, device):
+    """One iteration of the reference's hyper-parameter fit (models.py:145-158: 200 Adam iterations of factorisation + MLL +
+    gradient per update_model, agent.py:84-87) at N = 10 000: algp_set_hypers (an Adam step changed them) + algp_fit_step
+    (S, its factor and L^-T in one task-list launch, S^-1 = X X^T as one triangular-aware launch beside the two
+    substitutions, the pairwise gradient reduction).  N^3 flop in all (N^3/3 each for the factor, L^-T and X X^T)."""
+    out = {'workload': 'one iteration of GPR.fit at N = 10 000 (100 x 100 MoG field, D = 2): set_hypers + fit_step = factorisation + MLL + '
+                       'gradient w.r.t. the D + 2 log hyper-parameters; median of 5', 'by_dtype': {}}
+    for name, dt, peak in (('f64', np.float64, FP64_MATRIX_PEAK_TFLOPS), ('f32', np.float32, FP32_MATRIX_PEAK_TFLOPS)):
+        rng = np.random.RandomState(4)
+        grid, field = mog_field(100, 100, rng)
+        N = len(grid)
+        c = _hip.Context(dt, device=device)
+        try:
+            c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+            c.set_pool(grid)
+            c.set_train(np.arange(N), field + 0.1 * rng.standard_normal(N), np.full(N, 0.01))
+            c.fit_step()
+            ts = []
+            for it in range(5):
+                c.sync()
+                t0 = time.perf_counter()
+                c.set_hypers(np.log([3.0 + 0.01 * (it + 1), 3.0]), 0.0, np.log(1e-2))
+                mll, g = c.fit_step()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            c.prof_enable(True)
+            c.prof_reset()
+            c.fit_step()
+            pr = {k: c.prof_get(k) for k in ('kmat', 'dag_panel', 'chol_dag', 'gemm_other', 'trsv')}
+            c.prof_enable(False)
+            ms = float(np.median(ts))
+            tf = float(N) ** 3 / (ms * 1e-3) / 1e12
+            out['by_dtype'][name] = {
+                'ms_per_iteration': ms, 'iterations_ms': [round(t, 3) for t in ts], 'mll': mll, 'grad': [float(v) for v in g],
+                'factor_and_inverse_in_one_launch_ms': pr['dag_panel']['ms'] if pr['dag_panel']['launches'] else None,
+                'xxt_launch_ms': pr['gemm_other']['ms'], 'xxt_launches': pr['gemm_other']['launches'],
+                'substitutions_ms_beside_xxt': pr['trsv']['ms'], 'kernel_matrix_ms': pr['kmat']['ms'],
+                'roofline': {'bound': 'mfma', 'kernel': 'chol_dag_kernel + gemm_nt_kernel_dma4 (factor, L^-T, X X^T)', 'unit': 'TFLOP/s',
+                             'achieved': tf, 'peak': peak, 'frac': tf / peak,
+                             'note': 'N^3 flop (N^3/3 each for the factorisation, L^-T and X X^T) / the whole iteration\'s wall time'}}
+        finally:
+            c.close()
+    out['ms_per_iteration'] = out['by_dtype']['f64']['ms_per_iteration']
+    return out
+
+
 def sources_sha16():
     """Fingerprint of the kernel sources the PMC traffic figure belongs to (the GEMM and the solve that launches it)."""
     import hashlib
@@ -789,7 +834,8 @@ def main():
         if world == 1 and not args.no_extras:
             ctx.close()
             ctx = None
-            for name, fn in (('c3_fp32_10k', lambda: extra_c3(_hip, local_rank)),
+            for name, fn in (('fit_iteration', lambda: extra_fit(_hip, local_rank)),
+                             ('c3_fp32_10k', lambda: extra_c3(_hip, local_rank)),
                              ('c5_fp64_50k', lambda: extra_c5(_hip, local_rank, args.picks)),
                              ('mi_criterion', lambda: extra_mi(_hip, local_rank))):
                 t0 = time.perf_counter()

@@ -141,6 +141,11 @@ int algp_get_mll(algp_ctx* ctx, double* mll);                /* -1/2 y0'alpha - 
  * grad_out[D+2] = d MLL / d (log_lengthscale[0..D), log_outputscale, log_noise), NOT divided by N.
  * Needs a coordinate pool and a current factorisation.                                          */
 int algp_get_mll_grad(algp_ctx* ctx, double* grad_out);
+/* The device work of ONE iteration of GPR.fit (models.py:145-158: output = model(train_x); loss = -mll(output, train_y);
+ * loss.backward()) in one call, for the current hyper-parameters and train set: = algp_factorize + algp_get_mll +
+ * algp_get_mll_grad with the same values, but L^-T comes out of the launch that factors S (the identity rides along as a
+ * row panel of the task list) instead of from a separate launch sequence.  mll / grad_out[D+2] may each be NULL. */
+int algp_fit_step(algp_ctx* ctx, double* mll, double* grad_out);
 
 /* ---- candidates / test points: predictive_distribution (utils.py:293-319), greedy's pool ---
  * idx[M] pool indices.  A candidate that is itself in the train set (a mobile-sampled site,

@@ -180,3 +180,39 @@ def test_a_stall_in_the_solve_only_launch_is_reported_and_survivable():
     mu1, pv1 = c.posterior()
     assert np.array_equal(mu0, mu1) and np.array_equal(pv0, pv1)
     c.close()
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-8), (np.float32, 2e-2)], ids=['f64', 'f32'])
+@pytest.mark.parametrize('kernel', [_hip.KERNEL_RBF, _hip.KERNEL_MATERN15], ids=['rbf', 'matern'])
+def test_fit_step_with_the_identity_panel_against_the_three_calls_and_the_oracle(dtype, tol, kernel):
+    """algp_fit_step: X = L^-T rides along with the factorisation as an identity panel (mode 2: tile row e exists from
+    column e on), S^-1 = X X^T is one triangular-aware launch.  Same MLL and gradient as algp_factorize + algp_get_mll +
+    algp_get_mll_grad (which take the launch sequence for X) to rounding, as the oracle's closed form (models.py:147-148
+    through autograd in the reference; O.mll_and_grad), and the same bits in every run."""
+    rng = np.random.RandomState(21)
+    N = 1400
+    X = rng.uniform(0, 30, (N, 3))
+    y = np.sin(X[:, 0]) + 0.1 * rng.standard_normal(N)
+    var = rng.uniform(0.005, 0.05, N)
+    hyp = O.Hypers(np.log([1.3, 2.1, 0.8]), np.log(0.9), np.log(0.05), O.KERNEL_RBF if kernel == _hip.KERNEL_RBF else O.KERNEL_MATERN15)
+    c = _hip.Context(dtype)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise, kernel)
+    c.set_pool(X)
+    c.set_train(np.arange(N), y, var)
+    c.prof_enable(True)
+    c.prof_reset()
+    mll, g = c.fit_step()
+    assert c.prof_get('dag_panel')['launches'] == 1
+    c.prof_enable(False)
+    mll_b, g_b = c.fit_step()
+    assert mll == mll_b and np.array_equal(g, g_b)
+    c.factorize()
+    mll3, g3 = c.mll(), c.mll_grad()
+    assert mll3 == mll                                   # the factor does not depend on the panel
+    assert np.max(np.abs(g3 - g) / np.maximum(1.0, np.abs(g))) <= (1e-10 if dtype == np.float64 else 2e-3)
+    if kernel == _hip.KERNEL_RBF:
+        f0, go = O.mll_and_grad(hyp, X, y, var)          # the oracle's are per train point (the reference's loss is -MLL/N)
+        want = np.r_[go['log_lengthscale'], go['log_outputscale'], go['log_noise']] * N
+        assert abs(mll - f0 * N) <= tol * abs(f0 * N)
+        assert np.max(np.abs(g - want) / np.maximum(1.0, np.abs(want))) <= tol
+    c.close()
