@@ -39,9 +39,13 @@
 namespace algp {
 
 enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2, DAG_TU = 3 };
-constexpr int DAG_STRIPS = 4;                                 // row strips of a 128-row tile product on the chain
+#ifndef ALGP_DAG_STRIP_ROWS
+#define ALGP_DAG_STRIP_ROWS 32
+#endif
+constexpr int DAG_SR = ALGP_DAG_STRIP_ROWS;                   // rows of a strip: 16 or 32
+constexpr int DAG_STRIPS = 128 / DAG_SR;                      // row strips of a 128-row tile product on the chain
 constexpr int DAG_TEAM = 1 + DAG_STRIPS;                      // workgroups on the diagonal chain: leader + one helper per strip
-constexpr int DAG_CTRL = 16;                                  // control words
+constexpr int DAG_CTRL = 32;                                  // control words
 struct DagTask {
     int type, i, j, kk;                                        // kk = (k0 << 16) | k1
 };                                                             // DAG_TU: TRSM(i,j) and then UPD(i,j+1,j) by the same workgroup
@@ -316,30 +320,34 @@ __device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* count
     }
 }
 
-// ---- 32 x 128 strip product acc += A_strip B^T (A_strip: 32 rows, B: 128 rows, both k-contiguous): the chain's two
-// K = 128 products cut into four row strips, one per chain workgroup.  Same LDS-DMA pipeline as tile_mainloop; a stage
-// is 4 KB of A (wave w stages rows 8w..8w+7 with its lower 32 lanes; the upper lanes' copies land in the unused half
-// of the wave's 1 KB) + 8 KB of B; wave w owns output columns 32w..32w+31 (2 x 2 MFMA tiles).
-template <typename T>
+// ---- SR x 128 strip product acc += A_strip B^T (A_strip: SR = 16 or 32 rows, B: 128 rows, both k-contiguous): the
+// chain's K = 128 products cut into 128 / SR row strips, one per helper workgroup.  Same LDS-DMA pipeline as
+// tile_mainloop; a stage is the strip of A (32 rows: 4 KB, wave w stages rows 8w..8w+7 with its lower 32 lanes, the
+// upper lanes' copies land in the unused half of the wave's 1 KB; 16 rows: 1 KB, all of it by wave 0) + 8 KB of B;
+// wave w owns output columns 32w..32w+31 (SR / 16 x 2 MFMA tiles).  (Sixteen-row strips on eight helpers,
+// -DALGP_DAG_STRIP_ROWS=16, were measured in round 4: 7.21-7.24 vs 7.26-7.28 ms in fp64, 4.53-4.55 vs 4.42-4.59 ms in
+// fp32 at N = 10 000 -- within the spread; the strips' own time is not what the chain step waits for.)
+template <typename T, int SR>
 __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t lda, const T* B0, int64_t ldb, int nkt,
-                                               typename MF<T>::acc_t (&acc)[2][2]) {
+                                               typename MF<T>::acc_t (&acc)[SR / 16][2]) {
     using F = MF<T>;
     using chunk_t = typename F::chunk_t;
     constexpr int EPC = F::EPC;
     constexpr int BK = 4 * EPC;
-    constexpr int NST = 4, STB = 12288;
+    constexpr int NST = 4, STB = 12288, RT = SR / 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int srow = lane >> 2;
     const int bchunk = (lane & 3) ^ ((lane >> 4) & 3);
-    const int arow = 8 * wave + (srow & 7);
+    const int arow = SR == 32 ? 8 * wave + (srow & 7) : srow;
     const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
     const T* Ag = A0 + (int64_t)arow * lda + achunk * EPC;
     const T* Bg = B0 + (int64_t)(32 * wave + srow) * ldb + bchunk * EPC;
+    const bool stages_a = SR == 32 || wave == 0;                   // wave-uniform
     auto stage = [&](int st, int kt) {
-        char* As = smem + st * STB + wave * 1024;
+        char* As = smem + st * STB + (SR == 32 ? wave * 1024 : 0);
         char* Bs = smem + st * STB + 4096 + wave * 2048;
-        __builtin_amdgcn_global_load_lds((glb_vp)(Ag + (int64_t)kt * BK), (lds_vp)As, 16, 0, 0);
+        if (stages_a) __builtin_amdgcn_global_load_lds((glb_vp)(Ag + (int64_t)kt * BK), (lds_vp)As, 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((glb_vp)(Bg + (int64_t)(16 * i) * ldb + (int64_t)kt * BK),
@@ -347,8 +355,8 @@ __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t 
     };
     const int fr = lane & 15, fg = lane >> 4;
     const int coff = ((fg ^ ((fr >> 2) & 3)) << 4);
-    // A row 16 i + fr sits in the 1 KB of wave (2 i + (fr >> 3)), local row fr & 7
-    const int aoff = (fr >> 3) * 1024 + (fr & 7) * 64 + coff;
+    // 32 rows: A row 16 i + fr sits in the 1 KB of wave (2 i + (fr >> 3)), local row fr & 7; 16 rows: row fr of the one KB
+    const int aoff = SR == 32 ? (fr >> 3) * 1024 + (fr & 7) * 64 + coff : fr * 64 + coff;
     const int boff = 4096 + (32 * wave + fr) * 64 + coff;
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
@@ -356,15 +364,21 @@ __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t 
     int st = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const int younger = nkt - 1 - kt;
-        if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F76);       // vmcnt(6): three DMA per wave and stage
-        else if (younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        if (stages_a) {                                             // three DMA per stage in flight from this wave
+            if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F76);       // vmcnt(6)
+            else if (younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        } else {                                                    // two
+            if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F74);       // vmcnt(4)
+            else if (younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F72);  // vmcnt(2)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        chunk_t a[2], b[2];
+        chunk_t a[RT], b[2];
         const char* base = smem + st * STB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const chunk_t*>(base + aoff + i * 2048);
+        for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const chunk_t*>(base + aoff + i * 2048);
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const chunk_t*>(base + boff + j * 1024);
         if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);
@@ -373,23 +387,24 @@ __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t 
 #pragma unroll
             for (int e = 0; e < EPC; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
+                for (int i = 0; i < RT; ++i) acc[i][j] = F::mfma(a[i][e], b[j][e], acc[i][j]);
         st = (st + 1 == NST) ? 0 : st + 1;
     }
 }
-// strip `part` (rows 32 part .. 32 part + 31) of: UPD  tile (ti, tj) -= L_(ti,k) L_(tj,k)^T
-//                                                TRSM tile (ti, k) <- tile (ti, k) X_kk^T  (in place; tj unused)
+// strip `part` (rows SR part .. SR part + SR - 1) of: UPD  tile (ti, tj) -= L_(ti,k) L_(tj,k)^T
+//                                                      TRSM tile (ti, k) <- tile (ti, k) X_kk^T  (in place; tj unused)
 template <typename T>
 __device__ __forceinline__ void dag_strip_op(const DagArgs<T>& g, char* smem, bool upd, int part, int ti, int tj, int k) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
+    constexpr int SR = DAG_SR, RT = SR / 16;
     const int lane = threadIdx.x & 63, fr = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    T* Lik = g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)k * 128;      // the strip of tile (ti, k)
-    T* Out = upd ? g.L + ((int64_t)ti * 128 + 32 * part) * g.ld + (int64_t)tj * 128 : Lik;
-    acc_t acc[2][2];
+    T* Lik = g.L + ((int64_t)ti * 128 + SR * part) * g.ld + (int64_t)k * 128;      // the strip of tile (ti, k)
+    T* Out = upd ? g.L + ((int64_t)ti * 128 + SR * part) * g.ld + (int64_t)tj * 128 : Lik;
+    acc_t acc[RT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = i * 16 + F::row_of(lane, r);
@@ -397,10 +412,10 @@ __device__ __forceinline__ void dag_strip_op(const DagArgs<T>& g, char* smem, bo
             for (int j = 0; j < 2; ++j) acc[i][j][r] = upd ? -Out[gi * g.ld + wave * 32 + j * 16 + fr] : (T)0;
         }
     const T* B0 = upd ? g.L + (int64_t)tj * 128 * g.ld + (int64_t)k * 128 : g.invD + (int64_t)k * 128 * 128;
-    strip_mainloop<T>(smem, Lik, g.ld, B0, upd ? g.ld : 128, 128 / (4 * F::EPC), acc);
+    strip_mainloop<T, SR>(smem, Lik, g.ld, B0, upd ? g.ld : 128, 128 / (4 * F::EPC), acc);
     const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = i * 16 + F::row_of(lane, r);
@@ -915,7 +930,7 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
         if (c->dag_cache.size() >= 6) {                        // keep the six most recent shapes
             ALGP_HIP(hipStreamSynchronize(c->cur));
             for (DevBuf* b : {&c->dag_cache.front().tasks, &c->dag_cache.front().init})
-                if (b->p) { hipFree(b->p); c->dev_bytes -= (int64_t)b->cap; }
+                if (b->p) { (void)hipFree(b->p); c->dev_bytes -= (int64_t)b->cap; }
             c->dag_cache.erase(c->dag_cache.begin());
         }
         DagCache e;
@@ -936,7 +951,7 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
             for (int r = 0; r < mt; ++r)                       // a panel row counts its column steps from its first column
                 for (int j = shape.pstart(r); j < nt; ++j) ver[(size_t)(nt + r) * nt + j] = shape.pstart(r);
             int rc = ensure(c, e.init, state_bytes);
-            if (rc != ALGP_OK) { hipFree(e.tasks.p); c->dev_bytes -= (int64_t)e.tasks.cap; return rc; }
+            if (rc != ALGP_OK) { (void)hipFree(e.tasks.p); c->dev_bytes -= (int64_t)e.tasks.cap; return rc; }
             ALGP_HIP(hipMemcpy(e.init.p, st.data(), state_bytes, hipMemcpyHostToDevice));
         }
         c->dag_cache.push_back(e);
@@ -1033,8 +1048,8 @@ template int solve_dag_panel<float>(algp_ctx*, const float*, int64_t, int64_t, c
 
 void dag_release(algp_ctx* c) {
     for (auto& e : c->dag_cache) {
-        if (e.tasks.p) hipFree(e.tasks.p);
-        if (e.init.p) hipFree(e.init.p);
+        if (e.tasks.p) (void)hipFree(e.tasks.p);
+        if (e.init.p) (void)hipFree(e.init.p);
     }
     c->dag_cache.clear();
 }

@@ -614,7 +614,12 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
 template <typename T, bool PIVOTS = false>
 __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t lda, T* inv_out, double* logdet_acc,
                                                bool logdet_atomic, int* info, int64_t block_row0, double* pivots_out = nullptr) {
-    const int tid = threadIdx.x;
+    // tid through an opaque statement: inside a caller's loop (the one-launch factorisation's leader) everything this
+    // routine derives from the lane index -- three dozen per-lane masks and offsets -- is loop-invariant, and hoisted out
+    // of the loop it stays live across the whole routine on top of its own peak: 17 VGPRs spilled to scratch, reloaded in
+    // the middle of the leaf chain.  Recomputing them per call costs a few dozen VALU instructions.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) sh.bad = 0;                                  // ordered before the leaves by barrier B0

@@ -30,6 +30,8 @@
 #include "common.h"
 #include "mfma.h"
 #include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace algp {
 
@@ -240,6 +242,15 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
                               : 2.0 * 128.0 * 128.0 * (double)k * (double)tiles * batch;
     const double bytes = sizeof(T) * batch * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
                                               (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
+    {
+        // $ALGP_LAUNCH_LOG=<file>: one line per GEMM launch, in enqueue order (class m n k lower_only batch ktri): joined with a
+        // rocprofv3 kernel trace by dispatch order, it gives the trace the K its grid sizes do not show (tools/trace_shapes.py)
+        static FILE* launch_log = getenv("ALGP_LAUNCH_LOG") ? fopen(getenv("ALGP_LAUNCH_LOG"), "w") : nullptr;
+        if (launch_log) {
+            fprintf(launch_log, "%d %lld %lld %lld %d %d %d %d\n", klass, (long long)m, (long long)n, (long long)k, lower_only, batch, ktri, (int)sizeof(T));
+            fflush(launch_log);
+        }
+    }
     ProfScope ps(c, klass, flops, bytes);
     int64_t gx = tiles;
     if (ktri) {                                                    // 8 x the largest per-XCD share (rows x, x + 8, ... of XCD x)

@@ -1,0 +1,52 @@
+"""Joins a rocprofv3 --kernel-trace CSV of bench.py with the library's own launch log ($ALGP_LAUNCH_LOG: class m n k ... per
+GEMM launch, in enqueue order) by dispatch order and prints, for the candidate solve's GEMM launches (class 2), a table by
+launch shape (tiles x K): calls, summed duration, TFLOP/s executed -- and the sum of their durations per solve, the figure
+bench.py's roofline.serial_kernel_frac is formed from with HIP events.
+usage: python tools/trace_shapes.py <kernel_trace.csv> <launch_log.txt> <solves in the trace> [<bench line .json>]"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+trace, log, nsolves = sys.argv[1], sys.argv[2], int(sys.argv[3])
+rows = [r for r in csv.DictReader(open(trace)) if 'gemm_nt_kernel_dma4' in r['Kernel_Name']]
+rows.sort(key=lambda r: int(r['Dispatch_Id']))
+launches = [tuple(int(v) for v in ln.split()) for ln in open(log) if ln.strip()]
+if len(rows) != len(launches):
+    raise SystemExit('trace holds %d GEMM dispatches, the launch log %d lines' % (len(rows), len(launches)))
+shape = defaultdict(lambda: [0, 0.0, 0.0])
+tot_ns, tot_fl, n2 = 0, 0.0, 0
+first, last = None, None
+for r, (klass, m, n, k, lower, batch, ktri, es) in zip(rows, launches):
+    tiles = int(r['Grid_Size_X']) // 256
+    want = (m // 128) * (m // 128 + 1) // 2 if lower else (m // 128) * (n // 128)
+    if not ktri and tiles != want:
+        raise SystemExit('dispatch %s: grid of %d tiles, the log says %d x %d (%d tiles)' % (r['Dispatch_Id'], tiles, m, n, want))
+    if klass != 2:
+        continue
+    ns = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    fl = 2.0 * 128 * 128 * k * tiles * batch
+    s = shape[(tiles, k)]
+    s[0] += 1
+    s[1] += ns * 1e-6
+    s[2] += fl
+    tot_ns += ns
+    tot_fl += fl
+    n2 += 1
+print('candidate-solve GEMM launches (class GEMM_TRSM): %d in %d solves' % (n2, nsolves))
+print('%10s %7s %7s %11s %10s' % ('tiles', 'K', 'calls', 'sum ms', 'TFLOP/s'))
+for (tiles, k), (calls, ms, fl) in sorted(shape.items(), key=lambda kv: -kv[1][1]):
+    print('%10d %7d %7d %11.3f %10.1f' % (tiles, k, calls, ms, fl / (ms * 1e-3) / 1e12))
+per = tot_ns * 1e-6 / nsolves
+print('sum of launch durations per solve: %.2f ms (%d launches per solve); executed flop per solve %.4g -> %.1f TFLOP/s executed'
+      % (per, n2 // nsolves, tot_fl / nsolves, tot_fl / nsolves / (per * 1e-3) / 1e12))
+if len(sys.argv) > 4:
+    b = json.load(open(sys.argv[4]))
+    rf = b['roofline']
+    K = b['steps']
+    ev = rf['sum_launch_ms'] / K
+    print('bench line of the same process: HIP-event sum of the launches %.2f ms per solve (trace / events = %.3f); algorithmic N^2 M = %.4g flop'
+          % (ev, per / ev, rf['algorithmic_flops_per_step']))
+    print('  -> the launches back to back: %.1f TFLOP/s algorithmic = %.3f of %.1f by the trace, %.3f by the events'
+          % (rf['algorithmic_flops_per_step'] / (per * 1e-3) / 1e12, rf['algorithmic_flops_per_step'] / (per * 1e-3) / 1e12 / rf['peak'], rf['peak'],
+             rf['algorithmic_flops_per_step'] / (ev * 1e-3) / 1e12 / rf['peak']))
