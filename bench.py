@@ -541,7 +541,7 @@ def main():
                          'gloo all-gather handed to algp_comm_init_host with --backend gloo); torch: ShardedGreedy over '
                          'torch.distributed (the cross-check)')
     ap.add_argument('--cpu-train', type=int, default=6000)
-    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r03_traffic_pmc.json'))
+    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r04_traffic_pmc.json'))
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -1,4 +1,4 @@
-"""profiles/r03_traffic_pmc.json from the per-kernel counter summaries (tools/collect_profiles.sh -> pmc_by_kernel.json):
+"""profiles/r04_traffic_pmc.json from the per-kernel counter summaries (tools/collect_profiles.sh -> pmc_by_kernel.json):
 HBM-side bytes per launch of the dominant kernel (the MFMA GEMM of the candidate solve) and of the one-launch Cholesky,
 with the fingerprint of the kernel sources they were measured on -- bench.py reports `roofline.traffic` only when that
 fingerprint matches the sources it runs.
