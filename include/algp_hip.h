@@ -210,23 +210,31 @@ int algp_greedy(algp_ctx* ctx, int criterion, double static_std, double mobile_s
 int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen, double mobile_std, double* dH_out);
 
 /* ---- (e) multi-GPU: the loop over candidates (agent.py:317-347) cut into shards, one process and one ctx per GPU ----
- * Every rank factorises the same train set (algp_factorize) and holds a contiguous slice of the candidate list
- * (algp_set_candidates + algp_solve_candidates; a slice may be empty).  The only communication of the path is ONE
- * all-gather of 24 bytes per rank and pick -- (best local utility, its pool index, status) -- issued by the library on
- * the context's stream:
+ * Every rank factorises the same train set (algp_factorize / algp_fit_and_solve) and holds a contiguous slice of the
+ * candidate list (algp_set_candidates + a solve; a slice may be empty).  The only communication of the path is ONE
+ * all-gather per pick, issued by the library on the context's stream: each rank contributes 32 bytes -- (its best local
+ * utility, that candidate's pool index, a status word, the candidate's statistic) -- plus that candidate's row of V^T
+ * (Npad + 128 elements: ~80 KB at N = 10 000 fp64), so that a rank which does not own the winner copies the winner's row
+ * instead of rebuilding it from the factor ($ALGP_GATHER_ROWS=0: the 32 bytes only, rows rebuilt).
  * algp_comm_unique_id: 128 opaque bytes (ncclUniqueId); one rank calls it, the caller hands them to the others.
  * algp_comm_init: joins this ctx to an RCCL communicator (xGMI) of `nranks` ranks as `rank` (collective: every rank
  *   calls it).  RCCL is opened with dlopen here; without it these return ALGP_ERR_HIP and nothing else is affected.
  * algp_comm_init_host: the same loop over a transport the CALLER owns (MPI, gloo, shared memory): `fn(user, send, recv,
  *   bytes_per_rank)` must all-gather `bytes_per_rank` bytes of host memory in rank order and return 0; it is called
- *   once per pick (twice in the rare extra round) by every rank.  This is also how two ranks can share one card.
+ *   once per pick (twice in the rare extra round) by every rank; two stream synchronisations per pick instead of one.
+ *   This is also how two ranks can share one card.
+ * Both reserve the exchange's buffers for the current train set; algp_set_train re-reserves them when its size changes.
  * algp_greedy_sharded: k picks (entropy criterion; the MI criterion does not shard).  Per pick, stream-ordered and with
  *   a single read-back (40 bytes): each rank's best candidate resolved on the device (argmax, refresh of the rows
  *   whose bound can still win, argmax), the all-gather, the first maximum in rank order (= np.argmax over the
  *   concatenated scores, agent.py:349, shards being contiguous in rank order), then the commit of the winner on every
  *   rank (enqueued, not waited for).  picks_out: k pool indices (equal on all ranks); utilities_out: their k utilities,
- *   or NULL.  A rank that cannot take part in a pick (no solve, an allocation failure, ...) still joins the gather and
- *   reports its error code in the status word: EVERY rank then returns that code, nobody commits the pick, nobody hangs. */
+ *   or NULL.  A rank that cannot take part in a pick (no solve, an allocation failure, a failed pack launch, a stalled
+ *   one-launch kernel) still joins the gather and reports its error code in the status word: EVERY rank then returns that
+ *   code, nobody commits the pick, nobody hangs.  A commit that fails on one rank AFTER the exchange that chose the winner
+ *   is reported in that rank's status word of its next pick (every rank returns it from that call); after the LAST pick of
+ *   a call it is returned by that rank at once and reported again in the first exchange of its next call -- the one case
+ *   in which ranks leave a call with different codes (closing it would take a second collective per call). */
 typedef int (*algp_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
 int algp_comm_unique_id(void* out128);
 int algp_comm_init(algp_ctx* ctx, int nranks, int rank, const void* unique_id128);
