@@ -326,7 +326,10 @@ __device__ __forceinline__ void dag_publish_part(const DagArgs<T>& g, int* count
 // upper lanes' copies land in the unused half of the wave's 1 KB; 16 rows: 1 KB, all of it by wave 0) + 8 KB of B;
 // wave w owns output columns 32w..32w+31 (SR / 16 x 2 MFMA tiles).  (Sixteen-row strips on eight helpers,
 // -DALGP_DAG_STRIP_ROWS=16, were measured in round 4: 7.21-7.24 vs 7.26-7.28 ms in fp64, 4.53-4.55 vs 4.42-4.59 ms in
-// fp32 at N = 10 000 -- within the spread; the strips' own time is not what the chain step waits for.)
+// fp32 at N = 10 000 -- within the spread.  So was a one-shot form of the fp32 strip product -- all fragments of A and B
+// loaded straight into registers, one wait, no LDS, no k-loop: 5.3 + 5.4 us per step for the two products against 4.4 + 4.5
+// by the in-kernel stamps.  A strip product on the chain is the latency of fetching tiles another CU has just written
+// through to memory, not pipeline structure.)
 template <typename T, int SR>
 __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t lda, const T* B0, int64_t ldb, int nkt,
                                                typename MF<T>::acc_t (&acc)[SR / 16][2]) {
