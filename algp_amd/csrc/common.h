@@ -76,6 +76,36 @@ struct LazyPick {          // device copy of a committed pick for the lazy greed
 
 }  // namespace algp
 
+namespace algp {
+// exp(x) for the kernel values, x <= 0 in every use (-r^2/2, -sqrt(3) r): ONE definition for every kernel that evaluates
+// k(x, x') -- the matrix build, the lazy refresh's b', the path scores, the mean-only posterior, the MLL gradient -- so
+// that a value recomputed later has the bits of the one stored earlier.  fp64: Cody-Waite reduction x = k ln2 + r,
+// |r| <= ln2 / 2, Taylor to r^13 (truncation 4e-18), v_ldexp: ~20 instructions where the library routine takes ~55 (the
+// matrix build was VALU-bound on it: profiles/r02_valu_by_kernel.json); within 1 ulp of the correctly rounded value on
+// [-745, 0], exact at 0, underflows to 0 like it.  fp32: the library's.
+__device__ __forceinline__ float kexp(float x) { return expf(x); }
+__device__ __forceinline__ double kexp(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;                          // 1/13!
+    p = __builtin_fma(p, r, 2.0876756987868098979e-09);            // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441718775e-08);            // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985890653e-07);            // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985892511e-06);            // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587301566e-05);            // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841253e-04);            // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889419e-03);            // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332177e-03);            // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664354e-02);            // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666665741e-01);            // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+}  // namespace algp
+
 struct algp_ctx {
     int device = 0;
     int dtype = ALGP_F64;

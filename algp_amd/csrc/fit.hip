@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256) void mll_grad_kernel(const T* Sinv, int64_t ld
             const double m = (i == j) ? 1.0 : 2.0;               // symmetric: off-diagonal pairs count twice
             T kv, dk;                                            // dk * u_d^2 = dK/dlog ls_d
             if (kernel == ALGP_KERNEL_RBF) {
-                kv = os * exp((T)-0.5 * r2);
+                kv = os * kexp((T)-0.5 * r2);
                 dk = kv;
             } else {
                 const T a = sqrt(r2) * (T)1.7320508075688772;
-                const T e = exp(-a);
+                const T e = kexp(-a);
                 kv = os * ((T)1 + a) * e;
                 dk = (T)3 * os * e;
             }

@@ -4,13 +4,15 @@
 // Replaces GPR.cov_mat (reference models.py:161-181): gpytorch materialises an n1 x n2 x D
 // difference tensor, then np.diag(var) and np.eye(n) allocate two more dense n x n arrays just to
 // add a diagonal (models.py:175-180).  Here every output element is produced once, in registers,
-// and stored once: the kernel is HBM-write bound (s * n1 * n2 bytes).
+// and stored once: the kernel is HBM-write bound (s * n1 * n2 bytes; 4.6 TB/s of stores at the bench's sizes since
+// round 4: 4 KiB-contiguous rows per workgroup, the rows' coordinates staged in LDS, the short fp64 exp of common.h --
+// 2.5 -> 2.0 ms per step; non-temporal stores and deeper unrolling: no further change).
 //
 // Layout: coordinates are pre-scaled by 1/lengthscale and zero padded to DP in {2,4,8} columns
 // (scale_coords), so the distance loop is fully unrolled.  A 256-thread workgroup produces a
-// 32-row x (64*VEC)-column tile: each lane owns VEC = 16 B / sizeof(T) adjacent columns (its
-// column coordinates stay in registers), each wave walks 8 rows whose coordinates are wave-uniform
-// loads; every store instruction of a wave writes 1 KiB contiguous.
+// 32-row x (256*VEC)-column tile: each lane owns VEC = 16 B / sizeof(T) adjacent columns (its
+// column coordinates stay in registers), the four waves sit side by side and walk the same 32 rows
+// (coordinates are wave-uniform loads): every row of the tile is written as 4 KiB contiguous.
 #include "common.h"
 
 namespace algp {
@@ -53,19 +55,19 @@ struct KmatArgs {
 
 template <typename T>
 __device__ __forceinline__ T kval(int kernel, T os, T r2) {
-    if (kernel == ALGP_KERNEL_RBF) return os * exp((T)-0.5 * r2);
+    if (kernel == ALGP_KERNEL_RBF) return os * kexp((T)-0.5 * r2);
     const T r = sqrt(r2) * (T)1.7320508075688772;
-    return os * ((T)1 + r) * exp(-r);
+    return os * ((T)1 + r) * kexp(-r);
 }
 
 template <typename T, int DP>
 __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
     constexpr int VEC = Vec16<T>::N;
     using vec_t = typename Vec16<T>::type;
+    // the four waves of a workgroup sit side by side on the same 32 rows: every row of the tile is 4 KiB contiguous
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
-    if (c0 >= a.cols_pad) return;
-    const int64_t r0 = a.row_base + (int64_t)blockIdx.y * 32 + wave * 8;
+    const int64_t c0 = (((int64_t)blockIdx.x * 4 + wave) * 64 + lane) * VEC;
+    const int64_t r0 = a.row_base + (int64_t)blockIdx.y * 32;
 
     T xc[VEC][DP];
     int64_t pc[VEC];
@@ -84,19 +86,37 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
             for (int d = 0; d < DP; ++d) xc[v][d] = (T)0;
         }
     }
-#pragma unroll 1
-    for (int rr = 0; rr < 8; ++rr) {
+    // the 32 rows' unit flags, pool indices and coordinates once per workgroup into LDS: the row loop then has no
+    // dependent global loads (unit -> pool index -> coordinates were three serial scalar loads per row and wave)
+    __shared__ int s_u[32];
+    __shared__ int64_t s_p[32];
+    __shared__ T s_x[32][DP];
+    if (threadIdx.x < 32) {
+        const int64_t r = r0 + threadIdx.x;
+        int u = -1;
+        int64_t pr = 0;
+        if (r < a.rows) {
+            u = a.unit ? a.unit[r] : -1;
+            pr = a.ridx ? a.ridx[r] : r;
+        }
+        s_u[threadIdx.x] = u;
+        s_p[threadIdx.x] = pr;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) s_x[threadIdx.x][d] = (r < a.rows && u < 0 && !a.Cp) ? a.X1[pr * DP + d] : (T)0;
+    }
+    __syncthreads();
+    if (c0 >= a.cols_pad) return;
+#pragma unroll 2
+    for (int rr = 0; rr < 32; ++rr) {
         const int64_t r = r0 + rr;
         if (r >= a.rows_pad) break;
         vec_t o;
         if (r < a.rows) {
-            const int u = a.unit ? a.unit[r] : -1;
-            const int64_t pr = a.ridx ? a.ridx[r] : r;
+            const int u = s_u[rr];
+            const int64_t pr = s_p[rr];
             T xr[DP];
-            if (u < 0 && !a.Cp) {
 #pragma unroll
-                for (int d = 0; d < DP; ++d) xr[d] = a.X1[pr * DP + d];
-            }
+            for (int d = 0; d < DP; ++d) xr[d] = s_x[rr][d];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const int64_t c = c0 + v;
@@ -140,7 +160,7 @@ template <typename T>
 static int kmat_dispatch(algp_ctx* c, const KmatArgs<T>& a, int DP) {
     constexpr int VEC = Vec16<T>::N;
     if (a.rows_pad <= 0 || a.cols_pad <= 0) return ALGP_OK;
-    const int64_t gx = (a.cols_pad + 64 * VEC - 1) / (64 * VEC);
+    const int64_t gx = (a.cols_pad + 256 * VEC - 1) / (256 * VEC);
     const int64_t gy = (a.rows_pad + 31) / 32;
     const double elems = (double)a.rows_pad * (double)a.cols_pad;
     ProfScope ps(c, ALGP_PROF_KMAT, elems * (3.0 * DP + 2.0), sizeof(T) * elems);

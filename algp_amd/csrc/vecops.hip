@@ -280,10 +280,10 @@ __device__ __forceinline__ T pick_bprime(bool unit, int64_t pj, const T* Xs, con
                 const T df = Xs[pick_pool * DP + d] - Xs[pj * DP + d];
                 r2 += df * df;
             }
-            if (kernel == ALGP_KERNEL_RBF) bp = os * exp((T)-0.5 * r2);
+            if (kernel == ALGP_KERNEL_RBF) bp = os * kexp((T)-0.5 * r2);
             else {
                 const T r = sqrt(r2) * (T)1.7320508075688772;
-                bp = os * ((T)1 + r) * exp(-r);
+                bp = os * ((T)1 + r) * kexp(-r);
             }
             if (pj == pick_pool) bp += noise;
         }
@@ -682,10 +682,10 @@ __global__ __launch_bounds__(256) void path_score_kernel(const int64_t* cpos, co
                     const double df = (double)Xs[pa * DP + d] - (double)Xs[pb * DP + d];
                     r2 += df * df;
                 }
-                if (kernel == ALGP_KERNEL_RBF) cab = os * exp(-0.5 * r2);
+                if (kernel == ALGP_KERNEL_RBF) cab = os * kexp(-0.5 * r2);
                 else {
                     const double r = sqrt(r2) * 1.7320508075688772;
-                    cab = os * (1.0 + r) * exp(-r);
+                    cab = os * (1.0 + r) * kexp(-r);
                 }
                 if (pa == pb) cab += noise;
             }
@@ -761,10 +761,10 @@ __global__ __launch_bounds__(256) void kgemv_kernel(int64_t M, const int64_t* qi
                 r2 += df * df;
             }
             T kv;
-            if (kernel == ALGP_KERNEL_RBF) kv = os * exp((T)-0.5 * r2);
+            if (kernel == ALGP_KERNEL_RBF) kv = os * kexp((T)-0.5 * r2);
             else {
                 const T r = sqrt(r2) * (T)1.7320508075688772;
-                kv = os * ((T)1 + r) * exp(-r);
+                kv = os * ((T)1 + r) * kexp(-r);
             }
             s += kv * alpha[a];
         }

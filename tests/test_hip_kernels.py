@@ -154,6 +154,33 @@ def test_kernel_matrix(ctxs, dt, D, kernel):
     assert c.kernel_matrix(x1[:1]).shape == (1, 1)
 
 
+def test_kernel_value_exp_within_two_ulp_down_to_underflow(ctxs):
+    """The fp64 kernel values go through the library's own exp (common.h: kexp -- Cody-Waite reduction, Taylor to r^13,
+    ldexp; the matrix build was VALU-bound on the general routine): element by element within 2 ulp of NumPy's exp over the
+    whole range an RBF value can take, exp(0) = 1 exactly, a clean underflow to 0 -- for the ScaleKernel(RBF) of
+    models.py:218 and the Matern-1.5 of models.py:219-220."""
+    c = ctxs[np.dtype(np.float64)]
+    rng = np.random.RandomState(1)
+    t = np.r_[0.0, np.sort(rng.uniform(0, 745.0, 30000)), np.linspace(700, 760, 2000)]
+    x2 = np.sqrt(2.0 * t)[:, None]
+    x1 = np.zeros((3, 1))
+    c.set_hypers(np.zeros(1), 0.0, np.log(1e-2), _hip.KERNEL_RBF)
+    K = c.kernel_matrix(x1, x2)[0]
+    ref = np.exp(-0.5 * (0.0 - x2[:, 0]) ** 2)
+    big = ref > 1e-290
+    ulp = np.abs(K[big] - ref[big]) / np.spacing(ref[big])
+    assert ulp.max() <= 2.0, ulp.max()
+    assert K[0] == 1.0
+    assert np.all(K[~big] <= 1.1e-290) and np.all(K >= 0) and K[-1] == 0.0
+    c.set_hypers(np.zeros(1), 0.0, np.log(1e-2), _hip.KERNEL_MATERN15)
+    r = np.r_[0.0, np.sort(rng.uniform(0, 400.0, 20000))]
+    Km = c.kernel_matrix(x1, r[:, None])[0]
+    a = r * 1.7320508075688772
+    refm = (1.0 + a) * np.exp(-a)
+    ok = refm > 1e-290
+    assert np.max(np.abs(Km[ok] - refm[ok]) / np.spacing(refm[ok])) <= 4.0
+
+
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('N,M,D', [(5, 3, 2), (50, 40, 2), (200, 100, 6), (300, 513, 2), (129, 1, 3)])
 def test_factor_and_posterior(ctxs, dt, N, M, D):
