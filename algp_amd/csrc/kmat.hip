@@ -60,7 +60,10 @@ __device__ __forceinline__ T kval(int kernel, T os, T r2) {
     return os * ((T)1 + r) * kexp(-r);
 }
 
-template <typename T, int DP>
+// EQ: entries whose row and column address the same pool site receive a diagonal term (the symmetric builds); without it
+// (the candidates' B^T, cross matrices) the index comparisons are not even compiled in -- they and the other per-element
+// bookkeeping were half of the kernel's VALU instructions, and the kernel is VALU-issue bound (profiles/r04_valu_by_kernel.json).
+template <typename T, int DP, bool EQ>
 __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
     constexpr int VEC = Vec16<T>::N;
     using vec_t = typename Vec16<T>::type;
@@ -71,11 +74,13 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
 
     T xc[VEC][DP];
     int64_t pc[VEC];
+    bool live[VEC];                                                // column inside the matrix (not padding): per lane, per launch
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const int64_t c = c0 + v;
         pc[v] = -1;
-        if (c < a.cols) {
+        live[v] = c < a.cols;
+        if (live[v]) {
             pc[v] = a.cidx ? a.cidx[c] : c;
             if (!a.Cp) {
 #pragma unroll
@@ -106,51 +111,57 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
     }
     __syncthreads();
     if (c0 >= a.cols_pad) return;
+    const int64_t cend = c0 + VEC;                                 // this lane's columns are [c0, cend)
 #pragma unroll 2
     for (int rr = 0; rr < 32; ++rr) {
         const int64_t r = r0 + rr;
         if (r >= a.rows_pad) break;
         vec_t o;
-        if (r < a.rows) {
-            const int u = s_u[rr];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = (T)0;
+        // the row's facts are wave-uniform: told so to the compiler, its branches become scalar branches
+        const int u = __builtin_amdgcn_readfirstlane(s_u[rr]);
+        if (r < a.rows && u < 0) {
             const int64_t pr = s_p[rr];
-            T xr[DP];
+            if (a.Cp) {
 #pragma unroll
-            for (int d = 0; d < DP; ++d) xr[d] = s_x[rr][d];
+                for (int v = 0; v < VEC; ++v)
+                    if (live[v]) o[v] = a.Cp[pr * a.n_pool + pc[v]];
+            } else {
+                T xr[DP];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const int64_t c = c0 + v;
-                T val = (T)0;
-                if (c < a.cols) {
-                    if (u >= 0) {
-                        val = (c + a.col_shift == (int64_t)u) ? (T)1 : (T)0;
-                    } else {
-                        if (a.Cp) {
-                            val = a.Cp[pr * a.n_pool + pc[v]];
-                        } else {
-                            T r2 = (T)0;
+                for (int d = 0; d < DP; ++d) xr[d] = s_x[rr][d];
 #pragma unroll
-                            for (int d = 0; d < DP; ++d) {
-                                const T df = xr[d] - xc[v][d];
-                                r2 += df * df;
-                            }
-                            val = kval<T>(a.kernel, a.outputscale, r2);
-                        }
-                        if (a.same_pool && pr == pc[v]) {
-                            val += a.noise_on_equal;
-                            // the per-row term only on the row's own diagonal entry: two train rows may address the
-                            // same site (independent measurements), and their cross entry is C(i,i) without it
-                            if (a.diag_add && c == r + a.ident_shift) val += a.diag_add[r];
-                        }
+                for (int v = 0; v < VEC; ++v) {
+                    T r2 = (T)0;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        const T df = xr[d] - xc[v][d];
+                        r2 += df * df;
                     }
-                } else if (a.identity_pad && c == r + a.ident_shift) {
-                    val = (T)1;
+                    const T val = kval<T>(a.kernel, a.outputscale, r2);
+                    o[v] = live[v] ? val : (T)0;
                 }
-                o[v] = val;
             }
-        } else {
+            if (EQ) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) o[v] = (a.identity_pad && (c0 + v) == r + a.ident_shift) ? (T)1 : (T)0;
+                for (int v = 0; v < VEC; ++v)
+                    if (live[v] && a.same_pool && pr == pc[v]) {
+                        o[v] += a.noise_on_equal;
+                        // the per-row term only on the row's own diagonal entry: two train rows may address the
+                        // same site (independent measurements), and their cross entry is C(i,i) without it
+                        if (a.diag_add && c0 + v == r + a.ident_shift) o[v] += a.diag_add[r];
+                    }
+            }
+        } else if (r < a.rows) {
+            // a unit row e_u (a candidate that is a train site): one 1 in global column u
+            const int64_t cu = (int64_t)u - a.col_shift;
+            if (cu >= c0 && cu < cend && cu < a.cols) o[(int)(cu - c0)] = (T)1;
+        }
+        if (a.identity_pad) {
+            // the padded diagonal: (r, r + shift) for rows and columns beyond the matrix
+            const int64_t cd = r + a.ident_shift;
+            if (cd >= c0 && cd < cend && (cd >= a.cols || r >= a.rows)) o[(int)(cd - c0)] = (T)1;
         }
         *reinterpret_cast<vec_t*>(a.out + r * a.ldo + c0) = o;
     }
@@ -170,9 +181,16 @@ static int kmat_dispatch(algp_ctx* c, const KmatArgs<T>& a, int DP) {
         const int64_t ny = (gy - y0 < ymax) ? gy - y0 : ymax;
         b.row_base = y0 * 32;
         dim3 grid((unsigned)gx, (unsigned)ny);
-        if (DP == 2) hipLaunchKernelGGL((kmat_kernel<T, 2>), grid, dim3(256), 0, c->cur, b);
-        else if (DP == 4) hipLaunchKernelGGL((kmat_kernel<T, 4>), grid, dim3(256), 0, c->cur, b);
-        else hipLaunchKernelGGL((kmat_kernel<T, 8>), grid, dim3(256), 0, c->cur, b);
+        const bool eq = a.same_pool && (a.noise_on_equal != (T)0 || a.diag_add != nullptr);
+        if (eq) {
+            if (DP == 2) hipLaunchKernelGGL((kmat_kernel<T, 2, true>), grid, dim3(256), 0, c->cur, b);
+            else if (DP == 4) hipLaunchKernelGGL((kmat_kernel<T, 4, true>), grid, dim3(256), 0, c->cur, b);
+            else hipLaunchKernelGGL((kmat_kernel<T, 8, true>), grid, dim3(256), 0, c->cur, b);
+        } else {
+            if (DP == 2) hipLaunchKernelGGL((kmat_kernel<T, 2, false>), grid, dim3(256), 0, c->cur, b);
+            else if (DP == 4) hipLaunchKernelGGL((kmat_kernel<T, 4, false>), grid, dim3(256), 0, c->cur, b);
+            else hipLaunchKernelGGL((kmat_kernel<T, 8, false>), grid, dim3(256), 0, c->cur, b);
+        }
     }
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
