@@ -96,9 +96,12 @@ __device__ __forceinline__ T pick3(T t, bool use_t, T dv, bool use_d) {
 // Diagnostic builds only (tools/diag_test.hip): cycle stamps of thread 0 at phase boundaries.
 #ifdef ALGP_POTRF_STAMPS
 __device__ unsigned long long g_potrf_stamps[64];
+__device__ unsigned long long g_potrf_stamps_w[64];             // bulk wave 1 (threads 64..127), four per panel
 #define ALGP_STAMP(k) do { if (threadIdx.x == 0) g_potrf_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ALGP_STAMPW(k) do { if (threadIdx.x == 64) g_potrf_stamps_w[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ALGP_STAMP(k) do { } while (0)
+#define ALGP_STAMPW(k) do { } while (0)
 #endif
 
 constexpr int DBS = 16 * 17;                                   // elements per stored block
@@ -499,7 +502,9 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
 #pragma unroll
         for (int q = 0; q < 4; ++q) tacc[m][q] = (T)0;
     for (int p = 0; p < 8; ++p) {
+        ALGP_STAMPW(4 * p + 0);
         diag_barrier();                                        // B2(p): leaf p is done
+        ALGP_STAMPW(4 * p + 1);
         // ================= the short section wave 0 waits for =================
         const int own = p < 7 ? 1 + diag_diag_index(p + 1) % 3 : 0;
         const bool mine = own == w1 + 1;
@@ -537,6 +542,9 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
         }
         if (mine) {
             // the last update of block (p+1, p+1) with the L_(p+1)p just written, then the block to LDS for the next leaf
+            // (feeding this update from the accumulator of the transposed panel product instead -- no LDS round trip between the
+            // two products -- was measured in round 4: the section stays at ~1 900 cycles (fp32), it is the 16-20 MFMAs and
+            // three LDS round trips every bulk wave has in it, not the owner's chain)
             const Frag<T> f = frag_rows<T>(sh.S + LBLK(p + 1, p), li, lg, true);
 #pragma unroll
             for (int u = 0; u < 12; ++u)
@@ -548,7 +556,9 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
         } else if (p < 6) {
             diag_two_panel_blocks<T>(sh, p, diag_panel_slot(w1 + 1, own), lane);
         }
+        ALGP_STAMPW(4 * p + 2);
         diag_barrier();                                        // Bx(p)
+        ALGP_STAMPW(4 * p + 3);
         // ================= in the shadow of leaf p+1 =================
         if (p < 7) {
             // rank-16 update with panel p of every block right of it (block (p+1, p+1) has had its own), block by

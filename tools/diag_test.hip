@@ -82,6 +82,14 @@ int run(const char* name, double tol) {
                 crit += st[8 + 3 * p + 2] - st[8 + 3 * p + 1];
                 if (p < 7) bx += st[8 + 3 * (p + 1)] - st[8 + 3 * p + 2];
             }
+            unsigned long long sw[64];
+            hipMemcpyFromSymbol(sw, HIP_SYMBOL(algp::g_potrf_stamps_w), sizeof(sw));
+            printf("  per panel, cycles: wave 0 [leaf | B2 wait + its panel products | Bx wait]   bulk wave 1 [shadow work since Bx | B2 wait | section | Bx wait]\n");
+            for (int p = 0; p < 8; ++p)
+                printf("    p%d: w0 %5llu %5llu %5llu   w1 %5llu %5llu %5llu %5llu   (leaf ends %lld cycles after wave 1 reaches B2)\n", p,
+                       st[8 + 3 * p + 1] - st[8 + 3 * p], st[8 + 3 * p + 2] - st[8 + 3 * p + 1], p < 7 ? st[8 + 3 * (p + 1)] - st[8 + 3 * p + 2] : 0ull,
+                       p > 0 ? sw[4 * p] - sw[4 * (p - 1) + 3] : 0ull, sw[4 * p + 1] - sw[4 * p], sw[4 * p + 2] - sw[4 * p + 1], sw[4 * p + 3] - sw[4 * p + 2],
+                       (long long)st[8 + 3 * p + 1] - (long long)sw[4 * p]);
             printf("  8 leaves %llu cycles; B2 + panel products %llu; wait for the next diagonal block (7x) %llu; start -> first leaf %llu; last leaf done -> end %llu\n",
                    leaf, crit, bx, st[8] - st[0], st[7] - st[8 + 3 * 7 + 1]);
         }
