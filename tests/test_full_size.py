@@ -152,6 +152,97 @@ def test_c4_10000_x_100000_scoring_properties():
     c.close()
 
 
+def test_c4_one_rank_of_eight_fit_and_solve_in_one_launch_and_remote_commits():
+    """BASELINE config 4 as ONE of its eight ranks sees it: N = 10 000 train points, the rank's 12 500 of the 100 000
+    candidates.  (i) algp_fit_and_solve -- factor and V^T out of one task-list launch -- against SciPy's triangular solves
+    from the factor on sampled candidates (the 1e-5 bar of north_star with five digits to spare) and, to rounding, against
+    the two-phase path; (ii) algp_greedy_sharded as rank 5 of 8 over a host gather that fabricates the seven absent ranks
+    (their true winners: utility, statistic and row of V^T taken from a one-rank run over all candidates, agent.py:313-354
+    being one loop over them): the same four picks, and after the four commits -- two of them remote, rows copied out of the
+    gather -- every utility of the shard equals the one-rank run's to rounding."""
+    import struct
+    from scipy.linalg import solve_triangular
+    from algp_amd.sharded import partition
+    X, f, rng = field(100, 100)
+    N, M = len(X), 100000
+    ii, jj = np.meshgrid(np.arange(400), np.arange(250), indexing='ij')
+    Xc = np.vstack([(ii.ravel() + 0.37) * 0.25, (jj.ravel() + 0.41) * 0.4]).T[:M]
+    pool = np.vstack([X, Xc])
+    is_static = rng.uniform(size=N) < 0.5
+    var = np.where(is_static, 0.01, 1.0)
+    y = np.maximum(f + rng.standard_normal(N) * np.sqrt(var), 0)
+    cand = np.arange(N, N + M)
+    c = _hip.Context(np.float64)
+    c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+    c.set_pool(pool)
+    c.set_train(np.arange(N), y, var)
+    # the one-rank run: picks, utilities, and what each winner's owner would put into the gather
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.fit_and_solve()
+    picks, ut = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4, want_utilities=True)
+    picks = [int(q) for q in picks]
+    util = [float(np.nanmax(ut[q])) for q in range(4)]
+    rows = [c.debug_get_pick(q) for q in range(4)]
+    u_after = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    del ut
+    world, r = 8, 5
+    parts = partition(M, world)
+    lo, hi = parts[r]
+    owners = [next(s for s, (a, b) in enumerate(parts) if a <= (q - N) < b) for q in picks]
+    assert any(o != r for o in owners)
+    c.set_candidates(cand[lo:hi], prior_includes_noise=True)
+    c.prof_enable(True)
+    c.prof_reset()
+    c.fit_and_solve()
+    assert c.prof_get('dag_panel')['launches'] == 1 and c.prof_get('gemm_trsm')['launches'] == 0
+    c.prof_enable(False)
+    mu, pv = c.posterior()
+    L = c.factor()
+    samp = rng.permutation(hi - lo)[:64]
+    B = O.kernel_matrix(HYP, X, Xc[lo:hi][samp])
+    V = solve_triangular(L, B, lower=True)
+    z = solve_triangular(L, y - y.mean(), lower=True)
+    assert np.max(np.abs(pv[samp] - (HYP.outputscale + HYP.noise - np.sum(V * V, axis=0)))) < 1e-10
+    assert np.max(np.abs(mu[samp] - (y.mean() + V.T @ z))) < 1e-9
+    assert np.all(pv > 0) and np.all(pv <= HYP.outputscale + HYP.noise + 1e-12)
+    c.factorize()
+    c.solve_candidates()
+    mu2, pv2 = c.posterior()
+    assert np.max(np.abs(mu2 - mu)) < 1e-10 and np.max(np.abs(pv2 - pv)) < 1e-10
+    # (ii) rank 5 of 8
+    state = {'q': 0}
+
+    def gather(send):
+        pb = len(send)
+        q = min(state['q'], 3)
+        buf = bytearray(world * pb)
+        for s_ in range(world):
+            buf[s_ * pb:s_ * pb + 32] = struct.pack('<4d', float('-inf'), -1.0, 0.0, 0.0)
+        if owners[q] != r:
+            row, d = rows[q]
+            o = owners[q] * pb
+            buf[o:o + 32] = struct.pack('<4d', util[q], float(picks[q]), 0.0, d)
+            buf[o + 32:o + 32 + row.nbytes] = row.tobytes()
+        buf[r * pb:(r + 1) * pb] = send
+        if struct.unpack_from('<d', send, 16)[0] == 0.0:
+            state['q'] += 1
+        return bytes(buf)
+
+    c.comm_init_host(world, r, gather)
+    try:
+        c.fit_and_solve()
+        got, gut = c.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 4, want_utilities=True)
+        assert [int(q) for q in got] == picks
+        assert np.max(np.abs(np.asarray(gut) - np.asarray(util))) < 1e-11
+        u_sh = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+    finally:
+        c.comm_destroy()
+    ref = u_after[lo:hi]
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(u_sh)) and np.max(np.abs(u_sh[fin] - ref[fin])) < 1e-10
+    c.close()
+
+
 def test_c5_50000_points_fp64_consistency():
     """C5 size on one GPU (L = 20 GB): two independent routes to the posterior mean agree
     (V^T z after the blocked TRSM vs the fused kernel-GEMV with alpha = L^-T z), variances are
