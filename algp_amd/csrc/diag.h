@@ -130,16 +130,30 @@ __device__ __forceinline__ void diag_block_of(int t, int& bi, int& bk) {
 // Column step j with pivot d_j: f = (e_j - v[j]) / d_j  (e_j = 1 only in X lane j), then v[c] += u_c f for c > j
 // with u_c = A lane c's v[j] (wave-uniform).  In the A lanes this is the unscaled right-looking update
 // a[c] -= a_rj a_cj / d_j; in the X lanes v[i] accumulates s_i = sum_k U_ik Z_k of Z = U^-1 (U = L diag(sqrt d)).
+// gsrc != null (leaf 0 only): the block's rows come straight from global memory (leading dimension ld) instead of from
+// the LDS image -- leaf 0 then runs while the other waves are still loading their blocks and staging block column 0.
 template <typename T>
-__device__ __forceinline__ void diag_leaf(DiagShared<T>& sh, int p, int lane) {
+__device__ __forceinline__ void diag_leaf(DiagShared<T>& sh, int p, int lane, const T* gsrc = nullptr, int64_t ld = 0) {
     const int li = lane & 31, r = li & 15;                     // lanes 32-63 shadow lanes 0-31 and keep the pivots
     const bool isX = li >= 16;
     T* blk = sh.S + LBLK(p, p);
     T v[16];
+    if (gsrc) {
+        constexpr int VEC = 16 / sizeof(T);
+        typedef T vec_t __attribute__((ext_vector_type(VEC)));
+        const T* row = gsrc + (int64_t)r * ld;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const T t = blk[r * 17 + c];
-        v[c] = isX ? (T)0 : t;
+        for (int c = 0; c < 16; c += VEC) {
+            const vec_t t = *reinterpret_cast<const vec_t*>(row + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[c + e] = isX ? (T)0 : t[e];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const T t = blk[r * 17 + c];
+            v[c] = isX ? (T)0 : t;
+        }
     }
     T dmine = (T)1;                                            // lane 32 + j keeps pivot d_j
 #pragma unroll
@@ -294,50 +308,61 @@ __device__ __forceinline__ void inv_store(DiagShared<T>& sh, int r0, int J, cons
     }
 }
 
-// ---- 16 x 16 block movers between the LDS image and global memory (one wave; 128-byte row segments in fp64) ----
-// lane (column li, group lg) moves rows lg + 4q.  Addresses are a wave-uniform base (block start + 4 q rows: scalar
-// arithmetic) plus ONE 32-bit per-lane offset (lg * ld + li): a 128-row tile spans far less than 4 GB.  Written as
-// row * ld per access, the compiler kept a 64-bit product per row alive across the whole panel loop (32 rows: 64
-// registers, spilled in the one-launch kernel).
+// ---- 16 x 16 block movers from the LDS image to global memory (one wave) ----
+// lane l moves the four consecutive elements (row l >> 2, columns 4 (l & 3) ..) as 16-byte WRITE-THROUGH stores
+// (buffer_store_dwordx4 ... sc1: one per lane in fp32, two in fp64) through a descriptor on the block's wave-uniform base;
+// the per-lane part of the address is one 32-bit byte offset.  Rounds 1-3 stored four scalars per lane (rows lg + 4q,
+// column li): four fabric writes where one does (a 4-byte sc1 store costs ~6x a 16-byte one per byte,
+// MI355X_MICROARCH.md), and the leader's publish waits for all of them to drain.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ void store_row4(T* g, int64_t ld, int lane, T v0, T v1, T v2, T v3);
+template <>
+__device__ __forceinline__ void store_row4<float>(float* g, int64_t ld, int lane, float v0, float v1, float v2, float v3) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, 0x7ffffff0, 0x00020000);
+    const int off = (int)(((uint32_t)(lane >> 2) * (uint32_t)ld + (uint32_t)(lane & 3) * 4u) * 4u);
+    const u32x4 v = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+}
+template <>
+__device__ __forceinline__ void store_row4<double>(double* g, int64_t ld, int lane, double v0, double v1, double v2, double v3) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, 0x7ffffff0, 0x00020000);
+    const int off = (int)(((uint32_t)(lane >> 2) * (uint32_t)ld + (uint32_t)(lane & 3) * 4u) * 8u);
+    const u32x4 a = {(unsigned)__double2loint(v0), (unsigned)__double2hiint(v0), (unsigned)__double2loint(v1), (unsigned)__double2hiint(v1)};
+    const u32x4 b = {(unsigned)__double2loint(v2), (unsigned)__double2hiint(v2), (unsigned)__double2loint(v3), (unsigned)__double2hiint(v3)};
+    __builtin_amdgcn_raw_buffer_store_b128(a, rs, off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(b, rs, off + 16, 0, 16);
+}
 template <typename T>
 __device__ __forceinline__ void store_block_rowmajor(const T* blk, T* g, int64_t ld, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
-    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st_wt(g + (int64_t)(4 * q) * ld + vo, blk[(lg + 4 * q) * 17 + li]);
+    const T* src = blk + (lane >> 2) * 17 + (lane & 3) * 4;
+    store_row4<T>(g, ld, lane, src[0], src[1], src[2], src[3]);
 }
 // the lower triangle of a diagonal block of L (zeros above the diagonal: the LDS upper part holds the leaf inverse)
 template <typename T>
 __device__ __forceinline__ void store_block_lower(const T* blk, T* g, int64_t ld, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
-    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = lg + 4 * q;
-        const T t = blk[row * 17 + li];
-        st_wt(g + (int64_t)(4 * q) * ld + vo, (li <= row) ? t : (T)0);
-    }
+    const int r = lane >> 2, c = (lane & 3) * 4;
+    const T* src = blk + r * 17 + c;
+    const T t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+    store_row4<T>(g, ld, lane, c <= r ? t0 : (T)0, c + 1 <= r ? t1 : (T)0, c + 2 <= r ? t2 : (T)0, c + 3 <= r ? t3 : (T)0);
 }
-// the leaf inverse X_II (transposed upper storage + dinv[]) as a dense lower-triangular block
+// the leaf inverse X_II (transposed upper storage + dinv[]) as a dense lower-triangular block: X[r][c] = D[c][r] for c < r
 template <typename T>
 __device__ __forceinline__ void store_block_leafinv(const DiagShared<T>& sh, int I, T* g, int64_t ld, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
-    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
+    const int r = lane >> 2, c = (lane & 3) * 4;
     const T* D = sh.S + LBLK(I, I);
-    const T dv = sh.dinv[16 * I + li];
+    const T dv = sh.dinv[16 * I + r];
+    T v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = lg + 4 * q;
-        const T t = D[li * 17 + row];                          // X[row][li] for li < row
-        st_wt(g + (int64_t)(4 * q) * ld + vo, (li < row) ? t : (li == row ? dv : (T)0));
+    for (int e = 0; e < 4; ++e) {
+        const T t = D[(c + e) * 17 + r];
+        v[e] = (c + e < r) ? t : (c + e == r ? dv : (T)0);
     }
+    store_row4<T>(g, ld, lane, v[0], v[1], v[2], v[3]);
 }
 template <typename T>
 __device__ __forceinline__ void store_block_zero(T* g, int64_t ld, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
-    const uint32_t vo = (uint32_t)lg * (uint32_t)ld + (uint32_t)li;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st_wt(g + (int64_t)(4 * q) * ld + vo, (T)0);
+    store_row4<T>(g, ld, lane, (T)0, (T)0, (T)0, (T)0);
 }
 
 // LDS traffic complete, then the workgroup barrier.  (Not __syncthreads(): that also drains vmcnt, and the bulk waves keep
@@ -402,17 +427,22 @@ __device__ __forceinline__ Frag<T> frag_leafinv(const DiagShared<T>& sh, int I, 
     }
     return f;
 }
-// B[k][j = li] = X_MJ[k][j] of the inverse under construction: a full block (M > J), the leaf inverse (M == J), zeros (M < J)
+// B[k][j = li] = X_MJ[k][j] of the inverse under construction: a full block (M > J), the leaf inverse (M == J), zeros (M < J).
+// M and J are wave-uniform, so the three cases are scalar branches: a full block -- most of them -- is four plain reads
+// with no per-lane masks (the masked one-size-fits-all form spent ~60 VALU instructions per three fragments: a third of
+// the time of the products of the inverse's rows, which overrun the leaf they are meant to hide behind from panel 4 on).
 template <typename T>
 __device__ __forceinline__ Frag<T> frag_xblock(const DiagShared<T>& sh, int M, int J, int li, int lg) {
     Frag<T> f;
-    const bool on = J <= M, leaf = J == M;
-    const T* blk = sh.S + (on ? LBLK(M, J) : 0);
-    const T dv = sh.dinv[16 * (on ? J : 0) + li];
+    if (J < M) {
+        const T* blk = sh.S + LBLK(M, J);
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const int k = 4 * lg + st;
-        f.v[st] = pick3<T>(blk[leaf ? li * 17 + k : k * 17 + li], on && (!leaf || k > li), dv, leaf && k == li);
+        for (int st = 0; st < 4; ++st) f.v[st] = blk[(4 * lg + st) * 17 + li];
+    } else if (J == M) {
+        f = frag_leafinv<T>(sh, J, li, lg, true);
+    } else {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) f.v[st] = (T)0;
     }
     return f;
 }
@@ -456,11 +486,18 @@ __device__ __forceinline__ void diag_two_panel_blocks(DiagShared<T>& sh, int p, 
 // ---- wave 0: the eight leaves, nothing else on its way.  Between leaf p and leaf p+1 it only sits out the short
 // section in which the others make block (p+1, p+1) final (and takes its share of the panel products).
 template <typename T>
-__device__ __forceinline__ void diag_leaf_wave(DiagShared<T>& sh, int lane) {
-    diag_barrier();                                            // B0: block column 0 is in LDS
+__device__ __forceinline__ void diag_leaf_wave(DiagShared<T>& sh, const T* A, int64_t lda, int lane) {
+    // Leaf 0 does not wait for the LDS image: its 16 x 16 block comes straight from global memory, so it runs beside the
+    // other waves' loads of the 36 blocks and their staging of block column 0 (which leaves block (0, 0) to this wave);
+    // barrier B0 (block column 0 in LDS) falls after it.
     for (int p = 0; p < 8; ++p) {
         ALGP_STAMP(8 + 3 * p + 0);
-        diag_leaf<T>(sh, p, lane);
+        if (p == 0) {
+            diag_leaf<T>(sh, 0, lane, A, lda);
+            diag_barrier();                                    // B0
+        } else {
+            diag_leaf<T>(sh, p, lane);
+        }
         ALGP_STAMP(8 + 3 * p + 1);
         diag_barrier();                                        // B2(p): L_pp, X_pp are in LDS
         if (p < 6) diag_two_panel_blocks<T>(sh, p, diag_panel_slot(0, 1 + diag_diag_index(p + 1) % 3), lane);
@@ -491,10 +528,10 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[u][q] = -(A + (int64_t)(16 * bis[u] + rstep * q) * lda + 16 * bks[u])[vo];
     }
-    // block column 0 -> LDS
+    // block column 0 -> LDS (block (0, 0) is wave 0's: its leaf reads it from global memory and writes L_00, X_00 there)
 #pragma unroll
     for (int u = 0; u < 12; ++u)
-        if (bks[u] == 0) block_to_lds<T>(sh.S + LBLK(bis[u], 0), acc[u], (T)-1, lane);
+        if (bks[u] == 0 && bis[u] != 0) block_to_lds<T>(sh.S + LBLK(bis[u], 0), acc[u], (T)-1, lane);
     diag_barrier();                                            // B0
     acc_t tacc[3];                                             // T_pJ = sum_K L_pK X_KJ of the inverse's row p, J = w1 + 3 m
 #pragma unroll
@@ -510,6 +547,9 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
         const bool mine = own == w1 + 1;
         // inverse row p: X_pJ = -X_pp T_pJ (J = w1, w1+3, w1+6 below p) goes over L_pJ -- row p of L went to global memory in
         // the previous shadow and every product that reads it is done.  A[i][k] = X_pp[i][k], k = the row of T this lane holds.
+        // (Round 4 measured two rearrangements of this section, neither kept: all of a wave's products as ONE batch of
+        // reads / MFMAs / writes -- 1 900 -> 1 760 cycles where the wave owns block (p+1, p+1), 1 840 -> 2 130 where it does not,
+        // block unchanged -- and the owner's last update fed from the accumulator of the transposed panel product.)
         acc_t xo[3];
         {
             T xa[4];
@@ -542,9 +582,6 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
         }
         if (mine) {
             // the last update of block (p+1, p+1) with the L_(p+1)p just written, then the block to LDS for the next leaf
-            // (feeding this update from the accumulator of the transposed panel product instead -- no LDS round trip between the
-            // two products -- was measured in round 4: the section stays at ~1 900 cycles (fp32), it is the 16-20 MFMAs and
-            // three LDS round trips every bulk wave has in it, not the owner's chain)
             const Frag<T> f = frag_rows<T>(sh.S + LBLK(p + 1, p), li, lg, true);
 #pragma unroll
             for (int u = 0; u < 12; ++u)
@@ -596,6 +633,9 @@ __device__ __forceinline__ void diag_bulk_wave(DiagShared<T>& sh, T* A, int64_t 
             for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tacc[m][q] = (T)0;
+            // (Reading term M + 1's fragments before issuing term M's MFMAs, by hand -- hipcc does not pipeline this loop, each
+            // term sits out its LDS round trip in front of its 12 MFMAs -- was measured in round 4: the block got SLOWER,
+            // 59 200 -> 67 100 cycles in fp32, 80 600 -> 103 000 in fp64: the branches of frag_xblock then wait per case.)
             for (int M = w1; M <= p; ++M) {
                 const Frag<T> fl = frag_rows<T>(sh.S + LBLK(p + 1, M), li, lg, true);
                 Frag<T> fx[3];
@@ -634,7 +674,7 @@ __device__ __forceinline__ void diag128_factor(DiagShared<T>& sh, T* A, int64_t 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) sh.bad = 0;                                  // ordered before the leaves by barrier B0
     ALGP_STAMP(0);
-    if (wave == 0) diag_leaf_wave<T>(sh, lane);
+    if (wave == 0) diag_leaf_wave<T>(sh, A, lda, lane);
     else if (wave == 1) diag_bulk_wave<T, 0>(sh, A, lda, inv_out, lane);
     else if (wave == 2) diag_bulk_wave<T, 1>(sh, A, lda, inv_out, lane);
     else diag_bulk_wave<T, 2>(sh, A, lda, inv_out, lane);
