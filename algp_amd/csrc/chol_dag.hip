@@ -763,11 +763,23 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
             if (!solve_only)
                 for (int i = j; i < nt; ++i)
                     if (!single || i > k + 2) upd(i, j, k0, k1);
+            if (single) return;
             for (int e = 0; e < mt; ++e) {
                 const int ps = shape.pstart(e);
                 if (ps < k1) upd(nt + e, j, std::max(k0, ps), k1);
             }
         };
+        // A panel row is on nobody's critical path: the single steps of its tile (i, j) -- columns [kf, j-1), one to four of
+        // them -- are ONE task of K = 128 .. 512, handed out when the last of those columns is solved (step j-2); the factor's
+        // own rows keep their single steps, which gate the chain.  (23.7 % of the folded list's tasks were such single steps.)
+        auto panel_near = [&](int j) {
+            const int kf = batched_until(j, W);
+            for (int e = 0; e < mt; ++e) {
+                const int k0 = std::max(kf, shape.pstart(e));
+                if (k0 < j - 1) upd(nt + e, j, k0, j - 1);
+            }
+        };
+        if (k + 2 < nt) panel_near(k + 2);
         for (int j = k + 1; j < nt; ++j) {
             const int kf = batched_until(j, W);
             if (k >= kf) {
