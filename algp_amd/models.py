@@ -232,12 +232,12 @@ class GPR(object):
         N, M = len(self._train_x), len(x)
         c.set_pool(np.vstack([self._train_x, x]))
         c.set_train(np.arange(N), self._train_y, self._train_var)
-        c.factorize()
         noise = float(np.exp(self.likelihood.log_noise.item()))
         if not (return_std or return_cov):
+            c.factorize()
             return c.posterior_mean(np.arange(N, N + M))
         c.set_candidates(np.arange(N, N + M), prior_includes_noise=False)
-        c.solve_candidates()
+        c.fit_and_solve()                                                        # factorisation + V^T in one launch where it fits
         mu, var = c.posterior()
         if return_std:                                                           # models.py:193 returns the variance
             return mu, var + self.dtype.type(noise)

@@ -51,12 +51,13 @@ def predictive_distribution(gp, train_x, train_y, test_x, train_var=None, test_v
     N, M = len(train_x), len(test_x)
     c.set_pool(np.vstack([train_x, test_x]))
     c.set_train(np.arange(N), train_y, train_var)              # mean-centring inside (utils.py:294)
-    c.factorize()                                              # replaces inv(cov_aa), utils.py:300
     test_idx = np.arange(N, N + M)
     if not (return_var or return_cov or return_mi):
+        c.factorize()                                          # replaces inv(cov_aa), utils.py:300
         return c.posterior_mean(test_idx)                      # mu only: no triangular solve needed
     c.set_candidates(test_idx, prior_includes_noise=False, extra_var=test_var)
-    c.solve_candidates()
+    c.fit_and_solve()                                          # the factorisation and V^T = B^T L^-T (utils.py:300-301): ONE task-list
+                                                               # launch up to 40 960 test sites, two phases beyond
     mu, var = c.posterior()
     res = None
     if return_var:

@@ -182,17 +182,25 @@ def extra_c3(_hip, device):
     c.set_pool(np.vstack([grid, test]))
     c.set_train(np.arange(N), field + 0.1 * rng.standard_normal(N), np.full(N, 0.01))
     c.set_candidates(np.arange(N, N + len(test)), prior_includes_noise=False)
+    reps = 3
+    # the step as algp_amd/utils.py:predictive_distribution runs it: the factorisation and the test sites' solve in one
+    # task-list launch
+    c.fit_and_solve()
+    c.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c.fit_and_solve()
+        mu, pv = c.posterior()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    # the same as two phases, for the factorisation's own kernel time (the roofline below) and the solve's (HIP events)
     c.factorize()
     c.solve_candidates()
     c.prof_enable(True)
     c.prof_reset()
-    reps = 3
-    t0 = time.perf_counter()
     for _ in range(reps):
         c.factorize()
         c.solve_candidates()
         mu, pv = c.posterior()
-    wall = (time.perf_counter() - t0) / reps * 1e3
     ch, dag, tr = c.prof_get('cholesky'), c.prof_get('chol_dag'), c.prof_get('trsm')
     st = c.cholesky_task_stats()
     c.prof_enable(False)
@@ -200,7 +208,8 @@ def extra_c3(_hip, device):
     chol_ms = ch['ms'] / reps
     dag_ms = dag['ms'] / reps
     out = {'workload': 'C3: 10 000-point field, fp32: fit (kernel build + Cholesky + alpha) + posterior on 10 000 sites',
-           'dtype': 'f32', 'ms_per_step': wall, 'fit_ms': chol_ms,
+           'dtype': 'f32', 'ms_per_step': wall, 'fit_and_posterior_in_one_launch': True,
+           'fit_ms': chol_ms,
            'cholesky_kernel_ms': dag_ms, 'cholesky_tflops': N ** 3 / 3.0 / (dag_ms * 1e-3) / 1e12 if dag_ms > 0 else None,
            'posterior_solve_ms': tr['ms'] / reps,
            'roofline': {'bound': 'mfma', 'kernel': 'chol_dag_kernel<float>', 'unit': 'TFLOP/s', 'peak': FP32_MATRIX_PEAK_TFLOPS}}
