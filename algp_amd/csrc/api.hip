@@ -84,6 +84,24 @@ void prof_end(algp_ctx* c) {
     if (--prof_depth > 0) return;
     hipEventRecord(c->pending.back().b, c->cur);
 }
+// A scope that is exactly one kernel launch: the two events ride on the dispatch itself (hipExtLaunchKernelGGL: its own begin
+// and end timestamps, the figures rocprofv3 reports) instead of two hipEventRecord barrier packets around it on the stream --
+// with ~470 GEMM launches per candidate solve those packets cost the step 2 % (bench.py: ms_per_step vs ms_per_step_unprofiled).
+// False: profiling is off or an outer scope is open -- launch plainly.
+bool prof_launch_events(algp_ctx* c, int klass, double flops, double bytes, hipEvent_t* a, hipEvent_t* b) {
+    if (!c->prof_on || prof_depth > 0) return false;
+    PendingEvent pe;
+    pe.a = get_event(c);
+    pe.b = get_event(c);
+    pe.klass = klass;
+    c->prof[klass].flops += flops;
+    c->prof[klass].bytes += bytes;
+    c->prof[klass].launches += 1;
+    c->pending.push_back(pe);
+    *a = pe.a;
+    *b = pe.b;
+    return true;
+}
 static thread_local int span_index = -1;
 void prof_span_begin(algp_ctx* c, int klass, double flops, double bytes) {
     if (!c->prof_on) return;

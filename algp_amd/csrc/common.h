@@ -234,6 +234,7 @@ int fail(algp_ctx* c, int code, const std::string& msg);
 int ensure(algp_ctx* c, DevBuf& b, size_t bytes);
 void prof_begin(algp_ctx* c, int klass, double flops, double bytes);
 void prof_end(algp_ctx* c);
+bool prof_launch_events(algp_ctx* c, int klass, double flops, double bytes, hipEvent_t* a, hipEvent_t* b);
 void prof_collect(algp_ctx* c);
 // un-nested wall-time span on the main stream (e.g. a whole candidate solve whose row chunks overlap on several streams)
 void prof_span_begin(algp_ctx* c, int klass, double flops, double bytes);

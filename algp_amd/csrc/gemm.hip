@@ -28,6 +28,7 @@
 //   16-byte aligned base pointers.  In-place use (D aliasing A) is safe iff n == 128: a
 //   workgroup then reads exactly the rows it later overwrites and finishes reading first.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "mfma.h"
 #include <algorithm>
 #include <stdio.h>
@@ -251,7 +252,6 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
             fflush(launch_log);
         }
     }
-    ProfScope ps(c, klass, flops, bytes);
     int64_t gx = tiles;
     if (ktri) {                                                    // 8 x the largest per-XCD share (rows x, x + 8, ... of XCD x)
         int64_t most = 0;
@@ -263,7 +263,11 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
         gx = 8 * most;
     }
     const dim3 grid((unsigned)gx, (unsigned)batch);
-    hipLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, g);
+    hipEvent_t ev_a, ev_b;
+    if (prof_launch_events(c, klass, flops, bytes, &ev_a, &ev_b))
+        hipExtLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, ev_a, ev_b, 0, g);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
