@@ -375,7 +375,7 @@ class Agent(object):
             A = np.where(sampled)[0]
             c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
             c.set_candidates(np.where(~static)[0], prior_includes_noise=True)
-            c.fit_and_solve()                                   # one task-list launch up to 40 960 candidates
+            c.fit_and_solve()                                   # one task-list launch up to 51 200 candidates
         picks = c.greedy(_CRIT[self.criterion], self.static_std, self.mobile_std, int(num_samples))
         return [int(p) for p in picks]
 

@@ -758,7 +758,7 @@ struct Impl {
                               p(c->Vt) + keep, ldc, 0, keep);
     }
 
-    // the solve proper, against the resident factor.  A from-scratch solve of 33 .. 320 tile rows (a rank's share of the
+    // the solve proper, against the resident factor.  A from-scratch solve of 33 .. 400 tile rows (a rank's share of the
     // candidates on 4-8 GPUs, a held-out set) runs as ONE task-list launch (chol_dag.hip without the factorisation's
     // own tasks; $ALGP_SOLVE_DAG=0: the launch sequences of potrf.hip); everything else is trsm_blocked.
     static int solve_run(algp_ctx* c, const SolvePlan& pl) {

@@ -328,7 +328,7 @@ template <typename T>
 int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc,
                      int* info);
 // Sizes the one-launch task list (chol_dag.hip) serves: the factor's tile count, and the tile rows of a panel carried along
-constexpr int64_t DAG_MIN_TILES = 8, DAG_MAX_TILES = 192, DAG_MAX_PANEL_TILES = 320;
+constexpr int64_t DAG_MIN_TILES = 8, DAG_MAX_TILES = 192, DAG_MAX_PANEL_TILES = 400;
 bool dag_enabled();       // $ALGP_CHOL_DAG != 0
 // The factorisation and P <- P L^-T in one launch (P: mpad rows riding along as extra block rows of the task list;
 // mode 1: dense rows, mode 2: P = I of the factor's size -> L^-T); and the same solve against a factor that is final.

@@ -57,7 +57,7 @@ def predictive_distribution(gp, train_x, train_y, test_x, train_var=None, test_v
         return c.posterior_mean(test_idx)                      # mu only: no triangular solve needed
     c.set_candidates(test_idx, prior_includes_noise=False, extra_var=test_var)
     c.fit_and_solve()                                          # the factorisation and V^T = B^T L^-T (utils.py:300-301): ONE task-list
-                                                               # launch up to 40 960 test sites, two phases beyond
+                                                               # launch up to 51 200 test sites, two phases beyond
     mu, var = c.posterior()
     res = None
     if return_var:

@@ -831,7 +831,7 @@ def main():
                                'scoring_only_* subtract the replicated fit timed on its own (fit_alone_ms) from the rank\'s step and '
                                'stage_ms_per_step.cholesky from the one-GPU step.  Not in it: RCCL\'s wire time for n x 80 KB per pick (the '
                                'host transport\'s two synchronisations, PCIe copies and Python callback are in it instead) and skew between '
-                               'ranks.  Up to 40 960 rows the fit and the solve are ONE task-list launch (fit_and_solve_in_one_launch).')
+                               'ranks.  Up to 51 200 rows the fit and the solve are ONE task-list launch (fit_and_solve_in_one_launch).')
                 out['strong_emulation'] = emu
         if weak is not None:
             out['weak_scaling'] = {'value': weak['total_c'] / (weak['elapsed'] / K), 'unit': 'candidates/s',

@@ -1,6 +1,6 @@
 """The row panel carried by the one-launch task list (algp_amd/csrc/chol_dag.hip, DagShape): algp_fit_and_solve puts the
 rows of B^T below the factorisation as extra block rows, so V^T = B^T L^-T (reference utils.py:300-301: cov_xa @ inv(cov_aa))
-comes out of the launch that factors S; a from-scratch algp_solve_candidates of 33 .. 320 tile rows runs the same list
+comes out of the launch that factors S; a from-scratch algp_solve_candidates of 33 .. 400 tile rows runs the same list
 without the factorisation's own tasks.  Both against the oracle's posterior (utils.py:293-319 as O.posterior_chol), against
 the launch sequences of potrf.hip they replace, across repetitions (bit-identical: every tile receives its updates in
 ascending k whatever the timing), with train-site candidates (unit right-hand sides), in fp64 and fp32."""

@@ -152,6 +152,43 @@ def test_c4_10000_x_100000_scoring_properties():
     c.close()
 
 
+def test_c4_one_rank_of_two_is_one_launch_at_the_task_lists_upper_end():
+    """The share of a rank of TWO: 50 000 of config 4's candidates = 391 tile rows, close to the 400 the task list carries
+    (beyond it: the three-stream sweep).  algp_fit_and_solve is one launch; against SciPy's triangular solves from the
+    factor on sampled candidates, and bit for bit against algp_factorize + algp_solve_candidates (the same tile
+    arithmetic in the same order, as two task lists)."""
+    from scipy.linalg import solve_triangular
+    X, f, rng = field(100, 100)
+    N, M = len(X), 50000
+    ii, jj = np.meshgrid(np.arange(400), np.arange(250), indexing='ij')
+    Xc = np.vstack([(ii.ravel() + 0.37) * 0.25, (jj.ravel() + 0.41) * 0.4]).T[50000:50000 + M]
+    var = np.where(rng.uniform(size=N) < 0.5, 0.01, 1.0)
+    y = np.maximum(f + rng.standard_normal(N) * np.sqrt(var), 0)
+    c = _hip.Context(np.float64)
+    c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+    c.set_pool(np.vstack([X, Xc]))
+    c.set_train(np.arange(N), y, var)
+    c.set_candidates(np.arange(N, N + M), prior_includes_noise=True)
+    c.prof_enable(True)
+    c.prof_reset()
+    c.fit_and_solve()
+    assert c.prof_get('dag_panel')['launches'] == 1 and c.prof_get('gemm_trsm')['launches'] == 0
+    c.prof_enable(False)
+    mu, pv = c.posterior()
+    L = c.factor()
+    samp = rng.permutation(M)[:64]
+    V = solve_triangular(L, O.kernel_matrix(HYP, X, Xc[samp]), lower=True)
+    z = solve_triangular(L, y - y.mean(), lower=True)
+    assert np.max(np.abs(pv[samp] - (HYP.outputscale + HYP.noise - np.sum(V * V, axis=0)))) < 1e-10
+    assert np.max(np.abs(mu[samp] - (y.mean() + V.T @ z))) < 1e-9
+    assert np.all(pv > 0) and np.all(pv <= HYP.outputscale + HYP.noise + 1e-12)
+    c.factorize()
+    c.solve_candidates()
+    mu2, pv2 = c.posterior()
+    assert np.array_equal(mu2, mu) and np.array_equal(pv2, pv)
+    c.close()
+
+
 def test_c4_one_rank_of_eight_fit_and_solve_in_one_launch_and_remote_commits():
     """BASELINE config 4 as ONE of its eight ranks sees it: N = 10 000 train points, the rank's 12 500 of the 100 000
     candidates.  (i) algp_fit_and_solve -- factor and V^T out of one task-list launch -- against SciPy's triangular solves

@@ -1,5 +1,5 @@
 """The candidate solve V^T = B^T L^-T picks its order by the number of candidate rows: up to 4 096 rows right-looking with
-K = 128 steps (potrf.hip), up to 40 960 rows ONE launch of the task list without the factorisation's own tasks
+K = 128 steps (potrf.hip), up to 51 200 rows ONE launch of the task list without the factorisation's own tasks
 (chol_dag.hip; $ALGP_SOLVE_DAG=0: right-looking over 512-column blocks on two streams, the "push"), beyond that
 left-looking in row chunks on three streams.  Every regime, at its edges, against the oracle's
 posterior (utils.py:293-319 as O.posterior_chol) on sampled candidates, in fp64 and fp32 -- and the regimes against each
@@ -36,7 +36,7 @@ def _setup(dtype, M, rng):
 @pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-9), (np.float32, 2e-3)], ids=['f64', 'f32'])
 def test_every_solve_order_matches_the_oracle_and_the_others(dtype, tol):
     rng = np.random.RandomState(5)
-    sizes = [4096, 4097, 12500, 40960, 40961]          # last of the short order, first / middle / last of the task list, first of the chunks
+    sizes = [4096, 4097, 12500, 51200, 51201]          # last of the short order, first / middle / last of the task list, first of the chunks
     c, pool, A, y, var, cidx = _setup(dtype, max(sizes), rng)
     samp = np.sort(rng.permutation(4096)[:192])       # candidates that every size contains
     ref = O.posterior_chol(HYP, pool[A], y, pool[cidx[samp]], var)
@@ -62,7 +62,7 @@ def test_row_chunk_counts_give_the_same_solution():
     """algp_debug_set_trsm_chunks (ALGP_TRSM_CHUNKS): one to four row-chunk streams of the left-looking order solve the
     same rows with the same arithmetic -- bit-identical posteriors."""
     rng = np.random.RandomState(6)
-    M = 41500
+    M = 51500                                  # beyond the task list's 400 tile rows
     c, pool, A, y, var, cidx = _setup(np.float64, M, rng)
     c.set_candidates(cidx, prior_includes_noise=False)
     out = []

@@ -154,6 +154,15 @@ int main(int argc, char** argv) {
         printf("CHECK OK: %d panel schedules (N/128 = %d..%d)\n", n, lo, hi);
         return 0;
     }
+    if (argc > 5 && !strcmp(argv[1], "--check-shape")) {
+        // one shape, e.g. the largest the library sends: --check-shape NT MT MODE SOLVE_ONLY
+        DagShape sh;
+        sh.nt = atoi(argv[2]); sh.mt = atoi(argv[3]); sh.mode = atoi(argv[4]); sh.solve_only = atoi(argv[5]) != 0;
+        for (int workers : {512, 2 * DAG_TEAM + 1})
+            if (!check(sh, 2, workers)) return 1;
+        printf("CHECK OK: shape nt %d mt %d mode %d solve_only %d\n", sh.nt, sh.mt, sh.mode, (int)sh.solve_only);
+        return 0;
+    }
     // dag_sched_probe NT [MT MODE SOLVE_ONLY]
     DagShape sh;
     sh.nt = argc > 1 ? atoi(argv[1]) : 79;

@@ -1,5 +1,5 @@
 """Times one rank's share of BASELINE config 4 -- N = 10 000 train points, M candidates -- as algp_fit_and_solve (fit + solve
-in ONE task-list launch up to 40 960 rows) and as algp_factorize + algp_solve_candidates, in the current environment
+in ONE task-list launch up to 51 200 rows) and as algp_factorize + algp_solve_candidates, in the current environment
 ($ALGP_FOLD, $ALGP_SOLVE_DAG select the paths).  python tools/fold_time.py [f64|f32] [M ...]"""
 import os
 import sys
