@@ -47,6 +47,47 @@ def test_posterior_random(seed):
     c.close()
 
 
+@pytest.mark.parametrize('seed', range(300, 314))
+def test_posterior_random_at_task_list_sizes(seed):
+    """The same parity statement where the one-launch task list serves (N/128 >= 8): random train-set and test-set sizes
+    around tile edges, the factorisation and the solve folded into one launch (algp_fit_and_solve: what
+    predictive_distribution calls, utils.py:293-319), as two task lists, and a solve too short for a list of its own."""
+    rng = np.random.RandomState(seed)
+    D = int(rng.choice([2, 3, 6]))
+    N = int(rng.choice([1024, 1025, 1151, 1152, 1300, 1793, 2304, 2900]))
+    M = int(rng.choice([1, 127, 129, 900, 4096, 4097, 5000]))
+    dt = np.float64 if rng.rand() < 0.6 else np.float32
+    tol = 1e-8 if dt == np.float64 else 3e-3
+    kernel = O.KERNEL_RBF if rng.rand() < 0.6 else O.KERNEL_MATERN15
+    X = rng.uniform(0, 5.0 * (N + M) ** (1.0 / D), (N + M, D))
+    hyp = O.Hypers(np.log(rng.uniform(1.5, 3.0, D)), float(rng.uniform(-0.3, 0.3)), float(np.log(rng.uniform(5e-3, 5e-2))), kernel=kernel)
+    y = 2.0 + np.sin(X[:N].sum(1)) + 0.1 * rng.standard_normal(N)
+    var = rng.choice([0.01, 1.0], N)
+    tvar = rng.choice([0.0, 0.01, 1.0], M) if rng.rand() < 0.5 else None
+    ref = O.posterior_chol(hyp, X[:N], y, X[N:], var, tvar)
+    c = _hip.Context(dt)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise, kernel=hyp.kernel)
+    c.set_pool(X)
+    c.set_train(np.arange(N), y, var)
+    c.set_candidates(np.arange(N, N + M), prior_includes_noise=False, extra_var=tvar)
+    out = []
+    for folded in (True, False):
+        if folded:
+            c.fit_and_solve()
+        else:
+            c.factorize()
+            c.solve_candidates()
+        mu, pv = c.posterior()
+        scale = max(1.0, np.max(np.abs(ref['mu'])))
+        assert np.max(np.abs(mu - ref['mu'])) < tol * scale, (folded, N, M)
+        assert np.max(np.abs(pv - ref['var'])) < tol * max(1.0, np.max(np.abs(ref['var']))), (folded, N, M)
+        assert abs(c.logdet() - ref['logdet']) < tol * max(1.0, abs(ref['logdet'])) * (1 if dt == np.float64 else 5)
+        out.append((mu, pv))
+    loose = 1e-10 if dt == np.float64 else 5e-4                  # the two routes against each other: rounding only
+    assert np.max(np.abs(out[0][0] - out[1][0])) <= loose * scale and np.max(np.abs(out[0][1] - out[1][1])) <= loose
+    c.close()
+
+
 @pytest.mark.parametrize('seed', range(100, 124))
 def test_greedy_random(seed):
     rng, D, N, M, dt, X, hyp = _case(seed)
