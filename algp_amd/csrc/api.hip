@@ -681,9 +681,12 @@ struct Impl {
         int64_t keep = 0;                    // leading columns of V^T that stay
         std::vector<int> kind;               // per candidate: its train row (a unit right-hand side) or -1
         std::vector<int64_t> became_unit;
+        bool carried_sums = false;           // solve_finish will carry the rows' sums from step to step (u, w form of z)
+        bool rowstat_done = false;           // solve_run's launches left the rows' sums per column tile in c->rowstat
     };
     static int solve_prepare(algp_ctx* c, int incremental, SolvePlan& pl) {
         const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad;
+        pl.carried_sums = incremental && c->uw_rows == N && c->uvec.p && c->wvec.p;
         const int64_t ldv = Npad + MAX_APPEND;
         int64_t keep = 0;
         if (incremental && c->Vt.p && c->vt_hyp_stamp == c->hyp_stamp && c->vt_prior_noise == c->prior_noise &&
@@ -761,7 +764,7 @@ struct Impl {
     // the solve proper, against the resident factor.  A from-scratch solve of 33 .. 400 tile rows (a rank's share of the
     // candidates on 4-8 GPUs, a held-out set) runs as ONE task-list launch (chol_dag.hip without the factorisation's
     // own tasks; $ALGP_SOLVE_DAG=0: the launch sequences of potrf.hip); everything else is trsm_blocked.
-    static int solve_run(algp_ctx* c, const SolvePlan& pl) {
+    static int solve_run(algp_ctx* c, SolvePlan& pl) {
         const bool solve_dag_on = !(getenv("ALGP_SOLVE_DAG") && atoi(getenv("ALGP_SOLVE_DAG")) == 0);   // read per call: tests flip it
         const int64_t Npad = c->Npad, Mpad = c->Mpad, ldc = c->ldv, keep = pl.keep;
         prof_span_begin(c, ALGP_PROF_TRSM, (double)(Npad - keep) * (double)(Npad + keep) * (double)Mpad,
@@ -769,8 +772,16 @@ struct Impl {
         int trc;
         if (solve_dag_on && keep == 0 && Mpad / NB > 32 && panel_fits(Npad, Mpad) && c->cur == c->stream)
             trc = solve_dag_panel<T>(c, p(c->L), Npad, c->Lld, p(c->invD), (int*)((double*)c->scal.p + SC_STALL), p(c->Vt), ldc, Mpad, 1);
-        else
-            trc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), Npad, c->Lld, p(c->invD), keep);
+        else {
+            // a from-scratch solve of more than 320 tile rows: its launches leave the rows' sums of v^2 and v z per column tile
+            // (utils.py:301-304 needs nothing else of V^T), the 8 GB pass over V^T at config 4 falls away
+            T* stat = nullptr;
+            const bool stats_on = !(getenv("ALGP_ROW_STATS") && atoi(getenv("ALGP_ROW_STATS")) == 0);      // read per call: tests flip it
+            if (stats_on && keep == 0 && !pl.carried_sums && ensure(c, c->rowstat, sizeof(T) * 2 * (size_t)(Npad / NB) * (size_t)Mpad) == ALGP_OK)
+                stat = p(c->rowstat);
+            trc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), Npad, c->Lld, p(c->invD), keep, p(c->z), stat,
+                                  Mpad, &pl.rowstat_done);
+        }
         prof_span_end(c);
         return trc;
     }
@@ -779,7 +790,7 @@ struct Impl {
         const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad, ldc = c->ldv, keep = pl.keep;
         T* ss = p(c->tvec);
         T* dot = ss + Mpad;
-        if (incremental && c->uw_rows == N && c->uvec.p && c->wvec.p) {
+        if (pl.carried_sums) {
             // the factor update maintains z = u - ybar w: carry sum v^2, sum v u, sum v w over the finished column
             // blocks of V^T from step to step and read only the new columns (a full pass is 40 GB at N = 50 000)
             const size_t need = sizeof(T) * 6 * (size_t)Mpad;            // 3 running sums + 3 sums of the open tail
@@ -804,7 +815,8 @@ struct Impl {
             c->uw_stable = N;
         } else {
             c->acc_cols = 0;
-            ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), M, ldc, Npad, p(c->z), ss, dot));
+            if (pl.rowstat_done) ALGP_TRY(rowstat_combine_launch<T>(c, p(c->rowstat), Mpad, (int)(Npad / NB), M, ss, dot));
+            else ALGP_TRY(rows_reduce_launch<T>(c, p(c->Vt), M, ldc, Npad, p(c->z), ss, dot));
         }
         const T prior = (T)(c->hyp.outputscale + (c->prior_noise ? c->hyp.noise : 0.0));
         ALGP_TRY(cand_finalize_launch<T>(c, M, (const int*)c->ckind.p, (const int64_t*)c->Cidx.p,
@@ -837,12 +849,12 @@ struct Impl {
         return solve_finish(c, incremental, alive_host, pl);
     }
 
-    // GP-fit + candidate solve of one planning step (bench.py's step).  Up to 320 x 128 candidate rows (a rank's share on
-    // 4-8 GPUs) the two are ONE launch: the rows of B^T are extra block rows of the factorisation's task list (TRSM / UPD
+    // GP-fit + candidate solve of one planning step (bench.py's step).  Up to 400 x 128 candidate rows (a rank's share on
+    // 2-8 GPUs) the two are ONE launch: the rows of B^T are extra block rows of the factorisation's task list (TRSM / UPD
     // tasks without a diagonal), so V^T = B^T L^-T comes out of the launch that factors S -- the candidates' tile products
     // fill the machine while the diagonal chain alone would leave it idle, and the 140 short launches of a separate
     // mid-sized solve disappear ($ALGP_FOLD=0: the two phases back to back).  Larger candidate sets keep the two phases:
-    // the factorisation, then the three-stream sweep of potrf.hip, which wins from ~40 000 rows on.  (Overlapping the two
+    // the factorisation, then the three-stream sweep of potrf.hip, which wins from ~55 000 rows on.  (Overlapping the two
     // as separate launch sequences on streams was measured in round 1 -- 207 vs 193 ms/step -- and removed.)
     static int fit_and_solve(algp_ctx* c) {
         const bool fold_on = !(getenv("ALGP_FOLD") && atoi(getenv("ALGP_FOLD")) == 0);                  // read per call: tests flip it

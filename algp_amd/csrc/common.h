@@ -155,6 +155,7 @@ struct algp_ctx {
     int64_t uw_stable = 0;               // leading entries of u, w unchanged since the row sums below were started
     // per candidate: sums over the kept columns [0, acc_cols) of V^T of v^2, v u, v w (incremental solve)
     algp::DevBuf acc3;
+    algp::DevBuf rowstat;                // per column tile of V^T: row sums of v^2 and v z left by the solve's own launches
     algp::DevBuf splitk;                 // partial products of split-K launches (skinny solves)
     std::vector<algp::DagCache> dag_cache;   // task lists of the dependency-driven Cholesky, per matrix size
     algp::DevBuf dag_state;              // its per-launch tile versions / control words / per-block log-determinants
@@ -299,7 +300,14 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
 template <typename T>
 int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
                            int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
-                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri = 0);
+                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri = 0, const T* stat_w = nullptr,
+                           T* stat_out = nullptr, int64_t stat_ld = 0);
+// D = alpha A B^T for ONE column tile (n = 128) and, per output row, the tile's sums of d^2 and of d * w[column] to
+// stat_out[row] and stat_out[stat_ld + row] (the candidate solve's last write of a column tile of V^T: its share of the
+// variance and the mean without a second pass over V^T)
+template <typename T>
+int gemm_nt_launch_stats(algp_ctx* c, int klass, int64_t m, int64_t k, T alpha, const T* A, int64_t lda, const T* B, int64_t ldb,
+                         T* D, int64_t ldd, const T* w, T* stat_out, int64_t stat_ld);
 // C (m x m, lower tiles) -= X X^T for a short, very wide X (m <= 512 rows, k columns): the k range is cut into
 // chunks that run as one batched launch, the partial products are summed in chunk order (deterministic)
 template <typename T>
@@ -340,8 +348,12 @@ int solve_dag_panel(algp_ctx* c, const T* L, int64_t npad, int64_t ld, const T* 
                     int mode);
 // X (mpad x npad, ld ldx) <- X * L^-T, in place
 template <typename T>
+// stat_out (with stat_w; or null): where every row takes the left-looking order from column 0 (more than 320 tile rows), the
+// launch that writes a column tile for the last time leaves the tile's row sums of x^2 and x * stat_w[column] at
+// stat_out[(2 tile + 0 / 1) * stat_ld + row]; *stats_done says whether that happened (else: take them in a pass over X)
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                 int64_t ldl, const T* invD, int64_t col_start = 0);
+                 int64_t ldl, const T* invD, int64_t col_start = 0, const T* stat_w = nullptr, T* stat_out = nullptr,
+                 int64_t stat_ld = 0, bool* stats_done = nullptr);
 // X (npad x npad, holding the identity) <- L^-T (upper triangular; zero parts are never touched)
 template <typename T>
 int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T* L, int64_t ldl, const T* invD);

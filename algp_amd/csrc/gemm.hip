@@ -49,10 +49,37 @@ struct GemmArgs {
     int lower_only;
     int ktri;                      // lower_only products of an UPPER-triangular operand with itself (X X^T, X = L^-T): row tile bm of
                                    // X is zero left of column 128 bm, so tile (bm, bn <= bm) sums over k >= 128 bm only
+    // STATS kernels only (the launches that write a column tile of V^T for the last time): per output row, the sums over
+    // the tile's 128 columns of d^2 and of d * stat_w[column] go to stat_out[0 / 1][row] (second index: stat_ld apart)
+    const T* stat_w;
+    T* stat_out;
+    int64_t stat_ld;
 };
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
+
+// sum over the 16 lanes of a DPP row (the lanes that share lane >> 4), left in every lane: four rotate-and-add steps on
+// the VALU (row_ror 8, 4, 2, 1), no LDS round trip (the same butterfly through __shfl_xor is 8 ds_bpermute per double with
+// a wait each: 10 us per output tile in the epilogue below)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <typename T>
+__device__ __forceinline__ T row16_sum(T x) {
+    x += dpp_row<0x128>(x);
+    x += dpp_row<0x124>(x);
+    x += dpp_row<0x122>(x);
+    x += dpp_row<0x121>(x);
+    return x;
+}
 
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA staging with FOUR stages of 64-byte rows (4 x 16 KB, two workgroups per CU) and hand-placed waits, so
@@ -62,7 +89,7 @@ typedef const __attribute__((address_space(1))) void* glb_vp;
 // LDS image per operand and stage: [128 rows][4 chunks of 16 B], chunk index XOR ((row>>2)&3): a
 // ds_read_b128 of 16 consecutive rows at one chunk index touches 16 distinct 16-byte bank groups.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
     constexpr int NST = 4;
     using F = MF<T>;
@@ -203,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
                     Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r] + beta * cv[r][j];
             }
         }
-    } else {
+    } else if (!STATS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -212,14 +239,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Db[gi * g.ldd + n0 + wc * 64 + j * 16 + fr] = alpha * acc[i][j][r];
             }
+    } else {
+        // The tile goes out and, with it, its row statistics (the candidate solve's variance and mean, reference
+        // utils.py:301-304: a second pass over V^T otherwise -- 8 GB at config 4).  A lane holds, of each of its 16 rows, the
+        // four columns fr + 16 j of this wave's half: sum them, fold the 16 lanes of a row (DPP rotations inside the
+        // 16-lane group), add the two column halves through LDS (free now), one store per row and statistic.  Fixed order:
+        // the same bits in every run.  (Row by row, stores and sums together: kept for a second loop the 64 products
+        // alpha * acc cost 20 spilled VGPRs.)
+        T wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = g.stat_w[n0 + wc * 64 + j * 16 + fr];
+        T* red = reinterpret_cast<T*>(smem);                       // [column half][row][2]
+        __syncthreads();                                           // every wave is done with the last stage
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 64 + i * 16 + F::row_of(lane, r);
+                T s2 = (T)0, sw = (T)0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const T d = alpha * acc[i][j][r];
+                    Db[(m0 + row) * g.ldd + n0 + wc * 64 + j * 16 + fr] = d;
+                    s2 += d * d;
+                    sw += d * wv[j];
+                }
+                s2 = row16_sum<T>(s2);
+                sw = row16_sum<T>(sw);
+                if (fr == 0) {
+                    red[(wc * 128 + row) * 2 + 0] = s2;
+                    red[(wc * 128 + row) * 2 + 1] = sw;
+                }
+            }
+        __syncthreads();
+        const int row = tid >> 1, q = tid & 1;
+        g.stat_out[(int64_t)q * g.stat_ld + m0 + row] = red[row * 2 + q] + red[(128 + row) * 2 + q];
     }
 }
 
 template <typename T>
 int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
                            int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
-                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri) {
+                           T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri, const T* stat_w, T* stat_out,
+                           int64_t stat_ld) {
     if (m <= 0 || n <= 0 || batch <= 0) return ALGP_OK;
+    if (stat_out && (beta != (T)0 || n != 128 || batch != 1 || lower_only || ktri))
+        return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: row statistics need one column tile, beta = 0, no batch");
     if (m % 128 || n % 128 || k % 128 || k <= 0 || lda % 4 || ldb % 4 || sA % 4 || sB % 4)
         return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: operands must be padded to multiples of 128");
     if (lower_only && m != n) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: lower_only needs a square output");
@@ -234,6 +299,9 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
     g.alpha = alpha; g.beta = beta;
     g.lower_only = lower_only;
     g.ktri = ktri;
+    g.stat_w = stat_w;
+    g.stat_out = stat_out;
+    g.stat_ld = stat_ld;
     if (ktri && (!lower_only || k != m)) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: ktri needs a square lower-only product with k == m");
     const int64_t tiles = lower_only ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffff) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: grid too large");
@@ -264,10 +332,14 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
     }
     const dim3 grid((unsigned)gx, (unsigned)batch);
     hipEvent_t ev_a, ev_b;
-    if (prof_launch_events(c, klass, flops, bytes, &ev_a, &ev_b))
-        hipExtLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, ev_a, ev_b, 0, g);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel_dma4<T>, grid, dim3(256), 0, c->cur, g);
+    const bool timed = prof_launch_events(c, klass, flops, bytes, &ev_a, &ev_b);
+    if (stat_out) {
+        if (timed) hipExtLaunchKernelGGL((gemm_nt_kernel_dma4<T, true>), grid, dim3(256), 0, c->cur, ev_a, ev_b, 0, g);
+        else hipLaunchKernelGGL((gemm_nt_kernel_dma4<T, true>), grid, dim3(256), 0, c->cur, g);
+    } else {
+        if (timed) hipExtLaunchKernelGGL((gemm_nt_kernel_dma4<T, false>), grid, dim3(256), 0, c->cur, ev_a, ev_b, 0, g);
+        else hipLaunchKernelGGL((gemm_nt_kernel_dma4<T, false>), grid, dim3(256), 0, c->cur, g);
+    }
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
@@ -277,8 +349,19 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
                    int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
                    int64_t ldd, int lower_only) {
     return gemm_nt_launch_batched<T>(c, klass, m, n, k, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, D, ldd, 0,
-                                     lower_only, 1, 0);
+                                     lower_only, 1, 0, nullptr, nullptr, 0);
 }
+// D = alpha A B^T for ONE column tile (n = 128), and per output row the sums of d^2 and d * w[column] over the tile
+template <typename T>
+int gemm_nt_launch_stats(algp_ctx* c, int klass, int64_t m, int64_t k, T alpha, const T* A, int64_t lda, const T* B, int64_t ldb,
+                         T* D, int64_t ldd, const T* w, T* stat_out, int64_t stat_ld) {
+    return gemm_nt_launch_batched<T>(c, klass, m, 128, k, alpha, A, lda, 0, B, ldb, 0, (T)0, nullptr, 0, 0, D, ldd, 0, 0, 1, 0, w,
+                                     stat_out, stat_ld);
+}
+template int gemm_nt_launch_stats<double>(algp_ctx*, int, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t,
+                                          double*, int64_t, const double*, double*, int64_t);
+template int gemm_nt_launch_stats<float>(algp_ctx*, int, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, float*,
+                                         int64_t, const float*, float*, int64_t);
 
 template int gemm_nt_launch<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
                                     const double*, int64_t, double, const double*, int64_t, double*, int64_t, int);
@@ -286,10 +369,10 @@ template int gemm_nt_launch<float>(algp_ctx*, int, int64_t, int64_t, int64_t, fl
                                    const float*, int64_t, float, const float*, int64_t, float*, int64_t, int);
 template int gemm_nt_launch_batched<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
                                             int64_t, const double*, int64_t, int64_t, double, const double*, int64_t,
-                                            int64_t, double*, int64_t, int64_t, int, int, int);
+                                            int64_t, double*, int64_t, int64_t, int, int, int, const double*, double*, int64_t);
 template int gemm_nt_launch_batched<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
                                            int64_t, const float*, int64_t, int64_t, float, const float*, int64_t, int64_t,
-                                           float*, int64_t, int64_t, int, int, int);
+                                           float*, int64_t, int64_t, int, int, int, const float*, float*, int64_t);
 
 // ---------------------------------------------------------------------------------------------
 // MFMA fragment-layout probe (exact integer data, asymmetric B).

@@ -132,7 +132,10 @@ template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*
 //   inside J, 128 columns at a time: X_k <- (X_k - X_{J0:k} L_{k,J0:k}^T) inv(L_kk)^T
 template <typename T>
 static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                     int64_t ldl, const T* invD, int64_t col_start, bool whole_solve) {
+                     int64_t ldl, const T* invD, int64_t col_start, bool whole_solve, const T* stat_w = nullptr,
+                     T* stat_out = nullptr, int64_t stat_ld = 0) {
+    // stat_out (left-looking order only, col_start == 0: trsm_blocked decides): the launch that writes a column tile of X for
+    // the last time also leaves the tile's row sums of x^2 and x * stat_w[column] at stat_out[(2 tile + 0 / 1) * stat_ld + row]
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
     if (mpad <= 32 * NB) {
         // A short X (a few test points): the left-looking order below would walk K up to npad inside
@@ -227,8 +230,12 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
             if (k0 > j0)
                 ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, k0 - j0, (T)-1, Xj, ldx, L + k0 * ldl + j0, ldl, (T)1,
                                            Xk, ldx, Xk, ldx, 0));
-            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, (T)0,
-                                       nullptr, 0, Xk, ldx, 0));
+            if (stat_out)
+                ALGP_TRY(gemm_nt_launch_stats<T>(c, klass, mpad, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, Xk, ldx,
+                                                 stat_w + k0, stat_out + 2 * (k0 / NB) * stat_ld, stat_ld));
+            else
+                ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, NB, NB, (T)1, Xk, ldx, invD + (k0 / NB) * NB * NB, NB, (T)0,
+                                           nullptr, 0, Xk, ldx, 0));
         }
     }
     return ALGP_OK;
@@ -286,8 +293,9 @@ template int trinv_upper<float>(algp_ctx*, int, float*, int64_t, int64_t, const 
 // traffic per solve at N = 10 000, M = 100 000 -- the big off-diagonal blocks of L fall out of the 4 MB L2s -- and removed.)
 template <typename T>
 static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                     int64_t ldl, const T* invD, int64_t col_start, bool whole_solve) {
-    return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, whole_solve);
+                     int64_t ldl, const T* invD, int64_t col_start, bool whole_solve, const T* stat_w = nullptr,
+                     T* stat_out = nullptr, int64_t stat_ld = 0) {
+    return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, whole_solve, stat_w, stat_out, stat_ld);
 }
 
 static hipEvent_t sync_event(algp_ctx* c, size_t i) {
@@ -305,14 +313,18 @@ static hipEvent_t sync_event(algp_ctx* c, size_t i) {
 // chunks' MFMA-bound GEMMs -- 84 % of the fp64 matrix peak against 78.5 % with the launches back to back on one stream.
 template <typename T>
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
-                 int64_t ldl, const T* invD, int64_t col_start) {
+                 int64_t ldl, const T* invD, int64_t col_start, const T* stat_w, T* stat_out, int64_t stat_ld, bool* stats_done) {
     const int64_t tiles = mpad / NB;
+    // row statistics ride along where every row goes through the left-looking order from its first column
+    const bool stats = stat_out && stat_w && col_start == 0 && tiles > TRSM_PUSH_TILES;
+    if (stats_done) *stats_done = stats;
+    if (!stats) stat_out = nullptr;
     hipStream_t streams[4] = {c->stream, c->stream2, c->stream3, c->stream4};
     int nch = c->trsm_chunks < 1 ? 1 : (c->trsm_chunks > 4 ? 4 : c->trsm_chunks);
     while (nch > 1 && (!streams[nch - 1] || tiles < 32 * nch)) --nch;
     if (col_start == 0 && tiles <= TRSM_PUSH_TILES) nch = 1;    // the right-looking order fills the machine by itself
     if (nch == 1 || c->cur != c->stream)
-        return trsm_rows<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, true);
+        return trsm_rows<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, true, stat_w, stat_out, stat_ld);
     ALGP_HIP(hipEventRecord(sync_event(c, 0), streams[0]));
     int rc = ALGP_OK;
     int64_t r0 = 0;
@@ -320,7 +332,9 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
         const int64_t rows = (k == 0) ? mpad - r0 : (tiles / nch) * NB;
         if (k > 0) ALGP_HIP(hipStreamWaitEvent(streams[k], sync_event(c, 0), 0));
         c->cur = streams[k];
-        if (rc == ALGP_OK) rc = trsm_rows<T>(c, klass, X + r0 * ldx, rows, ldx, L, npad, ldl, invD, col_start, false);
+        if (rc == ALGP_OK)
+            rc = trsm_rows<T>(c, klass, X + r0 * ldx, rows, ldx, L, npad, ldl, invD, col_start, false, stat_w,
+                              stat_out ? stat_out + r0 : nullptr, stat_ld);
         r0 += rows;
     }
     c->cur = streams[0];
@@ -332,9 +346,9 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
     return rc;
 }
 template int trsm_blocked<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, int64_t,
-                                  const double*, int64_t);
+                                  const double*, int64_t, const double*, double*, int64_t, bool*);
 template int trsm_blocked<float>(algp_ctx*, int, float*, int64_t, int64_t, const float*, int64_t, int64_t,
-                                 const float*, int64_t);
+                                 const float*, int64_t, const float*, float*, int64_t, bool*);
 
 // ---------------------------------------------------------------------------------------------
 // C -= X X^T for a short, very wide X (the R <= 512 new rows of a factor update against N kept columns).

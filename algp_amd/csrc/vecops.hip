@@ -157,6 +157,37 @@ int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int6
 template int rows_reduce_launch<double>(algp_ctx*, const double*, int64_t, int64_t, int64_t, const double*, double*, double*);
 template int rows_reduce_launch<float>(algp_ctx*, const float*, int64_t, int64_t, int64_t, const float*, float*, float*);
 
+// The row statistics the candidate solve left per column tile (gemm.hip, STATS: stat[(2 t + 0 / 1) * ld + row]) summed over
+// the tiles in ascending order: ss = sum v^2, dot = sum v z of every row, without a second pass over V^T.
+template <typename T>
+__global__ __launch_bounds__(256) void rowstat_combine_kernel(const T* stat, int64_t ld, int ntiles, int64_t rows, T* ss, T* dot) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;                                  // 0: sum v^2, 1: sum v z
+    if (j >= rows) return;
+    const T* p = stat + (int64_t)q * ld + j;
+    T s = (T)0;
+    int t = 0;
+    for (; t + 8 <= ntiles; t += 8) {                          // eight loads in flight, added in tile order
+        T v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[(int64_t)(2 * (t + e)) * ld];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    for (; t < ntiles; ++t) s += p[(int64_t)(2 * t) * ld];
+    (q == 0 ? ss : dot)[j] = s;
+}
+template <typename T>
+int rowstat_combine_launch(algp_ctx* c, const T* stat, int64_t ld, int ntiles, int64_t rows, T* ss, T* dot) {
+    if (rows <= 0) return ALGP_OK;
+    ProfScope ps(c, ALGP_PROF_ROWS, 2.0 * rows * ntiles, sizeof(T) * 2.0 * (double)rows * ntiles);
+    hipLaunchKernelGGL(rowstat_combine_kernel<T>, dim3((unsigned)((rows + 255) / 256), 2), dim3(256), 0, c->cur, stat, ld, ntiles, rows, ss, dot);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int rowstat_combine_launch<double>(algp_ctx*, const double*, int64_t, int, int64_t, double*, double*);
+template int rowstat_combine_launch<float>(algp_ctx*, const float*, int64_t, int, int64_t, float*, float*);
+
 // ---------------------------------------------------------------------------------------------
 // candidate finalize: dstat = prior - ss (ordinary) | ss (unit row: [S^-1]_jj); mu = ybar + dot
 // ---------------------------------------------------------------------------------------------

@@ -76,6 +76,31 @@ def test_row_chunk_counts_give_the_same_solution():
     c.close()
 
 
+def test_row_statistics_come_out_of_the_solves_own_launches(monkeypatch):
+    """Beyond the task list's range the launch that writes a column tile of V^T for the last time also leaves the tile's row
+    sums of v^2 and v z (gemm.hip, STATS), so variance and mean (utils.py:301-304) need no second pass over V^T: against the
+    pass ($ALGP_ROW_STATS=0) to rounding, in both precisions, and by the bytes the library books for the statistics."""
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        rng = np.random.RandomState(9)
+        M = 51500
+        c, pool, A, y, var, cidx = _setup(dtype, M, rng)
+        c.set_candidates(cidx, prior_includes_noise=False)
+        c.prof_enable(True)
+        out, booked = [], []
+        for flag in ('1', '0'):
+            monkeypatch.setenv('ALGP_ROW_STATS', flag)
+            c.prof_reset()
+            c.solve_candidates()
+            booked.append(c.prof_get('rows')['bytes'])
+            out.append(c.posterior())
+        monkeypatch.delenv('ALGP_ROW_STATS')
+        c.prof_enable(False)
+        assert booked[0] < 0.05 * booked[1]                  # 2 x 11 tiles of sums per row against the 1 408 columns of V^T
+        assert np.max(np.abs(out[0][0] - out[1][0])) <= tol * max(1.0, np.max(np.abs(out[1][0])))
+        assert np.max(np.abs(out[0][1] - out[1][1])) <= tol
+        c.close()
+
+
 def test_push_order_six_blocks_deep_against_the_oracle_and_one_stream(monkeypatch):
     """the right-looking order over 512-column blocks (potrf.hip; the fallback of the task-list solve for train
     sets beyond its range, selected here with ALGP_SOLVE_DAG=0) rotates four pairs of events between its two streams; with
