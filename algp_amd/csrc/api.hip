@@ -683,6 +683,9 @@ struct Impl {
         std::vector<int64_t> became_unit;
         bool carried_sums = false;           // solve_finish will carry the rows' sums from step to step (u, w form of z)
         bool rowstat_done = false;           // solve_run's launches left the rows' sums per column tile in c->rowstat
+        int nseg = 0;                        // > 0: only the new columns are solved (tail.hip), as 1-2 ranges [seg_c0, seg_c0 + seg_w)
+        int64_t seg_c0[2] = {0, 0};
+        int seg_w[2] = {0, 0};
     };
     static int solve_prepare(algp_ctx* c, int incremental, SolvePlan& pl) {
         const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad;
@@ -695,6 +698,29 @@ struct Impl {
             int64_t p0 = 0;
             while (p0 < lim && c->vt_fact_idx[p0] == c->fact_idx[p0] && c->vt_fact_var[p0] == c->fact_var[p0]) ++p0;
             keep = p0 / NB * NB;
+            // Rows were appended behind p0 unchanged ones: the columns left of p0 stay as they are (L's old rows do not change),
+            // so only [p0, N) has to be solved -- at 16-column granularity, as one or two ranges of at most 64 columns inside
+            // a 128-column block of the factor (tail.hip): HBM-bound, where re-solving the whole open 128-block walks all of
+            // V^T on the matrix cores at full tile width (28 -> see DESIGN ms per step at N = 50 000 x 100 000 candidates).
+            // $ALGP_TAIL_COLS=0: the 128-column blocks as before.  Small problems keep them too (nothing to gain).
+            const bool tail_on = !(getenv("ALGP_TAIL_COLS") && atoi(getenv("ALGP_TAIL_COLS")) == 0);    // read per call: tests flip it
+            if (tail_on && p0 >= 2048 && Mpad >= 2048 && c->cur == c->stream) {
+                const int64_t k16 = p0 / 16 * 16, c1 = round_up(N, 16);
+                int n = 0;
+                bool ok = c1 > k16;
+                for (int64_t a = k16; a < c1 && ok;) {
+                    const int64_t b = std::min<int64_t>(c1, (a / NB + 1) * NB);
+                    if (b - a > 64 || n == 2) { ok = false; break; }
+                    pl.seg_c0[n] = a;
+                    pl.seg_w[n] = (int)(b - a);
+                    ++n;
+                    a = b;
+                }
+                if (ok && n > 0) {
+                    pl.nseg = n;
+                    keep = k16;
+                }
+            }
         }
         // candidate kinds under the current train set
         std::vector<int>& kind = pl.kind;
@@ -715,6 +741,7 @@ struct Impl {
             }
             if (keep == 0) became_unit.clear();
         }
+        if (keep == 0) pl.nseg = 0;
         pl.keep = keep;
         c->solved = false;
         if (!c->Vt.p || c->ldv_cap < ldv || (keep == 0 && !incremental && c->ldv_cap != ldv) ||
@@ -769,8 +796,12 @@ struct Impl {
         const int64_t Npad = c->Npad, Mpad = c->Mpad, ldc = c->ldv, keep = pl.keep;
         prof_span_begin(c, ALGP_PROF_TRSM, (double)(Npad - keep) * (double)(Npad + keep) * (double)Mpad,
                         sizeof(T) * (double)Mpad * (double)Npad);
-        int trc;
-        if (solve_dag_on && keep == 0 && Mpad / NB > 32 && panel_fits(Npad, Mpad) && c->cur == c->stream)
+        int trc = ALGP_OK;
+        if (pl.nseg > 0) {
+            for (int q = 0; q < pl.nseg && trc == ALGP_OK; ++q)
+                trc = tail_cols_launch<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad,
+                                          p(c->invD) + (pl.seg_c0[q] / NB) * NB * NB, pl.seg_c0[q], pl.seg_w[q]);
+        } else if (solve_dag_on && keep == 0 && Mpad / NB > 32 && panel_fits(Npad, Mpad) && c->cur == c->stream)
             trc = solve_dag_panel<T>(c, p(c->L), Npad, c->Lld, p(c->invD), (int*)((double*)c->scal.p + SC_STALL), p(c->Vt), ldc, Mpad, 1);
         else {
             // a from-scratch solve of more than 320 tile rows: its launches leave the rows' sums of v^2 and v z per column tile

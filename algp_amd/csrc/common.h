@@ -354,6 +354,11 @@ template <typename T>
 int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                  int64_t ldl, const T* invD, int64_t col_start = 0, const T* stat_w = nullptr, T* stat_out = nullptr,
                  int64_t stat_ld = 0, bool* stats_done = nullptr);
+// columns [c0, c0 + w) of X <- the solution's new columns after rows c0.. were appended to L (tail.hip): c0 a multiple of 16,
+// w <= 64, inside one 128-column block whose explicit inverse is invD_blk; lrows = rows of L that exist
+template <typename T>
+int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t ldl, int64_t lrows, const T* invD_blk,
+                     int64_t c0, int w);
 // X (npad x npad, holding the identity) <- L^-T (upper triangular; zero parts are never touched)
 template <typename T>
 int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T* L, int64_t ldl, const T* invD);

@@ -182,6 +182,71 @@ def test_candidate_solve_reuses_columns_and_matches_scratch():
 
 
 @pytest.mark.parametrize('dtname', ['f64', 'f32'])
+def test_only_the_new_columns_are_solved_after_an_append(dtname, monkeypatch):
+    """After rows were appended behind >= 2 048 unchanged ones, algp_solve_candidates_update solves only the columns the
+    append added (tail.hip: one or two ranges of <= 64 columns, 16-aligned, each inside a 128-column block of the factor)
+    instead of the whole open 128-block.  Appends chosen to hit: one range whose first column is 16 (mod 32) -- the fp32
+    kernel's half k-tile --, two ranges across a block boundary with the first 64 wide, an append too wide for it (the
+    128-blocks again), a range ending on a block boundary.  Every step against a from-scratch context and against the
+    128-block order ($ALGP_TAIL_COLS=0) on a copy of the state."""
+    dt = np.float64 if dtname == 'f64' else np.float32
+    tol, loose = (1e-9, 1e-10) if dt == np.float64 else (3e-3, 3e-4)
+    rng = np.random.RandomState(4)
+    n, M = 2600, 4300
+    X = rng.uniform(0, 60, (n + M, 2))
+    y = np.sin(X[:, 0] / 4) + np.cos(X[:, 1] / 5) + 0.1 * rng.standard_normal(n + M)
+    cand = np.arange(n, n + M)
+
+    def ctx():
+        c = _hip.Context(dt)
+        c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+        c.set_pool(X)
+        return c
+
+    c, b = ctx(), ctx()                                        # b: the same steps with the 128-block order
+    idx = np.arange(2100)
+    v = rng.choice([0.01, 1.0], n)
+    for k, c_ in enumerate((c, b)):
+        c_.set_train(idx, y[idx], v[idx])
+        c_.factorize(incremental=True)
+        c_.set_candidates(cand, prior_includes_noise=False)
+        assert c_.solve_candidates(incremental=True) == 0
+    expect = [(20, 1, 2096), (60, 2, 2112), (70, 0, 2176), (50, 1, 2240), (14, 2, 2288)]      # rows added, tail launches, kept columns
+    for add, launches, kept_want in expect:
+        idx = np.arange(len(idx) + add)
+        for which, c_ in (('tail', c), ('blocks', b)):
+            if which == 'blocks':
+                monkeypatch.setenv('ALGP_TAIL_COLS', '0')
+            c_.set_train(idx, y[idx], v[idx])
+            c_.factorize(incremental=True)
+            c_.set_candidates(cand, prior_includes_noise=False)
+            c_.prof_enable(True)
+            c_.prof_reset()
+            kept = c_.solve_candidates(incremental=True)
+            got = c_.prof_get('gemm_trsm')['launches']
+            c_.prof_enable(False)
+            if which == 'blocks':
+                monkeypatch.delenv('ALGP_TAIL_COLS')
+                assert kept == (len(idx) - add) // 128 * 128
+            else:
+                assert kept == kept_want, (add, kept)
+                assert got == launches or (launches == 0 and got >= 2), (add, got)       # 0: too wide, the 128-blocks
+        f = ctx()
+        f.set_train(idx, y[idx], v[idx])
+        f.factorize()
+        f.set_candidates(cand, prior_includes_noise=False)
+        f.solve_candidates()
+        mu_f, pv_f = f.posterior()
+        f.close()
+        (mu, pv), (mu_b, pv_b) = c.posterior(), b.posterior()
+        scale = max(1.0, np.max(np.abs(mu_f)))
+        assert np.max(np.abs(mu - mu_f)) < tol * scale and np.max(np.abs(pv - pv_f)) < tol, (add, 'tail vs scratch')
+        assert np.max(np.abs(mu - mu_b)) < loose * scale and np.max(np.abs(pv - pv_b)) < loose, (add, 'tail vs blocks')
+    c.close()
+    b.close()
+
+
+@pytest.mark.parametrize('dtname', ['f64', 'f32'])
 def test_factor_update_takes_new_rows_from_resident_candidates(dtname):
     """New train sites that are resident (ordinary) candidates: their rows of L left of the tail block are the
     leading parts of their rows of V^T, so the update gathers them instead of solving against the kept
