@@ -701,7 +701,7 @@ struct Impl {
             // Rows were appended behind p0 unchanged ones: the columns left of p0 stay as they are (L's old rows do not change),
             // so only [p0, N) has to be solved -- at 16-column granularity, as one or two ranges of at most 64 columns inside
             // a 128-column block of the factor (tail.hip): HBM-bound, where re-solving the whole open 128-block walks all of
-            // V^T on the matrix cores at full tile width (28 -> see DESIGN ms per step at N = 50 000 x 100 000 candidates).
+            // V^T on the matrix cores at full tile width (28 -> 13 ms per step at N = 50 000 x 100 000 candidates).
             // $ALGP_TAIL_COLS=0: the 128-column blocks as before.  Small problems keep them too (nothing to gain).
             const bool tail_on = !(getenv("ALGP_TAIL_COLS") && atoi(getenv("ALGP_TAIL_COLS")) == 0);    // read per call: tests flip it
             if (tail_on && p0 >= 2048 && Mpad >= 2048 && c->cur == c->stream) {

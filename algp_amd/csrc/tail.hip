@@ -7,8 +7,8 @@
 // block -- one or two 128-wide output tiles whose products walk ALL of V^T (K = N: 40 GB at N = 50 000 x 100 000
 // candidates) on the matrix cores at full tile width, 24 ms where the data take 8 to stream.  Columns left of c0 do not
 // change when rows are appended (L's old rows do not), so only [c0, c1) is computed here, as a 64-wide product that is
-// HBM-bound by construction: a workgroup owns 128 candidate rows, streams them once through the four-stage LDS-DMA
-// pipeline of gemm.hip (64-byte k-tiles, three in flight) against the 64 new rows of L, and finishes the columns in its
+// HBM-bound by construction: a workgroup owns 128 candidate rows, streams them once through a three-stage LDS-DMA
+// pipeline (128-byte row pieces, see the kernel) against the 64 new rows of L, and finishes the columns in its
 // epilogue with the trailing block of the tail's explicit inverse (for a lower-triangular D, inv(D)[S, S] = inv(D[S, S])
 // for every diagonal range S): the accumulator of the first product is, as it lies in registers, the B operand of the
 // second (MFMA layouts, mfma.h), so nothing goes through LDS in between.
