@@ -157,6 +157,7 @@ struct algp_ctx {
     algp::DevBuf acc3;
     algp::DevBuf rowstat;                // per column tile of V^T: row sums of v^2 and v z left by the solve's own launches
     algp::DevBuf splitk;                 // partial products of split-K launches (skinny solves)
+    algp::DevBuf inv512, inv512_scr, trsm_tmp;   // candidate solve: explicit inverses of the factor's 512-column blocks, their scratch, mpad x 512
     std::vector<algp::DagCache> dag_cache;   // task lists of the dependency-driven Cholesky, per matrix size
     algp::DevBuf dag_state;              // its per-launch tile versions / control words / per-block log-determinants
     algp::DevBuf trsv_ctrl;              // ticket + per-block flags of the one-launch forward substitution (potrf.hip)
@@ -301,7 +302,12 @@ template <typename T>
 int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
                            int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
                            T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri = 0, const T* stat_w = nullptr,
-                           T* stat_out = nullptr, int64_t stat_ld = 0);
+                           T* stat_out = nullptr, int64_t stat_ld = 0, int kcut = 0);
+// D (m x n) = A B^T, B (n x n) lower triangular by 128-tiles (column tile c sums over k < 128 (c + 1)); stat_out or null: the
+// row statistics of every column tile written (stat_out[(2 tile + 0 / 1) * stat_ld + row])
+template <typename T>
+int gemm_nt_launch_tri(algp_ctx* c, int klass, int64_t m, int64_t n, const T* A, int64_t lda, const T* B, int64_t ldb, T* D,
+                       int64_t ldd, const T* w, T* stat_out, int64_t stat_ld);
 // D = alpha A B^T for ONE column tile (n = 128) and, per output row, the tile's sums of d^2 and of d * w[column] to
 // stat_out[row] and stat_out[stat_ld + row] (the candidate solve's last write of a column tile of V^T: its share of the
 // variance and the mean without a second pass over V^T)

@@ -49,8 +49,10 @@ struct GemmArgs {
     int lower_only;
     int ktri;                      // lower_only products of an UPPER-triangular operand with itself (X X^T, X = L^-T): row tile bm of
                                    // X is zero left of column 128 bm, so tile (bm, bn <= bm) sums over k >= 128 bm only
+    int kcut;                      // B is LOWER triangular by 128 x 128 tiles (X * inv(L_JJ)^T with an explicit block inverse): column
+                                   // tile bn sums over k < 128 (bn + 1) only
     // STATS kernels only (the launches that write a column tile of V^T for the last time): per output row, the sums over
-    // the tile's 128 columns of d^2 and of d * stat_w[column] go to stat_out[0 / 1][row] (second index: stat_ld apart)
+    // the tile's 128 columns of d^2 and of d * stat_w[column] go to stat_out[2 bn + 0 / 1][row] (second index: stat_ld apart)
     const T* stat_w;
     T* stat_out;
     int64_t stat_ld;
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
-    const int nkt = g.ktiles * 2 - kskip;                          // g.ktiles counts 128-byte tiles
+    int nkt = g.ktiles * 2 - kskip;                                // g.ktiles counts 128-byte tiles
+    if (g.kcut && (bn + 1) * (128 / BK) < nkt) nkt = (bn + 1) * (128 / BK);
     // prologue: tiles 0 .. NST-2 in flight
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
             }
         __syncthreads();
         const int row = tid >> 1, q = tid & 1;
-        g.stat_out[(int64_t)q * g.stat_ld + m0 + row] = red[row * 2 + q] + red[(128 + row) * 2 + q];
+        g.stat_out[(int64_t)(2 * bn + q) * g.stat_ld + m0 + row] = red[row * 2 + q] + red[(128 + row) * 2 + q];
     }
 }
 
@@ -281,10 +284,11 @@ template <typename T>
 int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
                            int64_t sA, const T* B, int64_t ldb, int64_t sB, T beta, const T* C, int64_t ldc, int64_t sC,
                            T* D, int64_t ldd, int64_t sD, int lower_only, int batch, int ktri, const T* stat_w, T* stat_out,
-                           int64_t stat_ld) {
+                           int64_t stat_ld, int kcut) {
     if (m <= 0 || n <= 0 || batch <= 0) return ALGP_OK;
-    if (stat_out && (beta != (T)0 || n != 128 || batch != 1 || lower_only || ktri))
-        return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: row statistics need one column tile, beta = 0, no batch");
+    if (stat_out && (beta != (T)0 || batch != 1 || lower_only || ktri))
+        return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: row statistics need beta = 0, no batch");
+    if (kcut && (k != n || lower_only || ktri)) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: kcut needs k == n");
     if (m % 128 || n % 128 || k % 128 || k <= 0 || lda % 4 || ldb % 4 || sA % 4 || sB % 4)
         return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: operands must be padded to multiples of 128");
     if (lower_only && m != n) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: lower_only needs a square output");
@@ -302,12 +306,14 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
     g.stat_w = stat_w;
     g.stat_out = stat_out;
     g.stat_ld = stat_ld;
+    g.kcut = kcut;
     if (ktri && (!lower_only || k != m)) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: ktri needs a square lower-only product with k == m");
     const int64_t tiles = lower_only ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffff) return fail(c, ALGP_ERR_BAD_ARG, "gemm_nt: grid too large");
     // ktri: tile row bm holds bm + 1 tiles of K = k - 128 bm: sum_bm (bm + 1)(tm - bm) = tm (tm + 1)(tm + 2) / 6 tile-steps of 128
     const double tm = (double)g.tiles_m;
     const double flops = ktri ? 2.0 * 128.0 * 128.0 * 128.0 * tm * (tm + 1.0) * (tm + 2.0) / 6.0 * batch
+                         : kcut ? 2.0 * 128.0 * 128.0 * 128.0 * tm * (double)g.tiles_n * (g.tiles_n + 1.0) / 2.0 * batch
                               : 2.0 * 128.0 * 128.0 * (double)k * (double)tiles * batch;
     const double bytes = sizeof(T) * batch * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
                                               (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
@@ -349,15 +355,27 @@ int gemm_nt_launch(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t k, T al
                    int64_t lda, const T* B, int64_t ldb, T beta, const T* C, int64_t ldc, T* D,
                    int64_t ldd, int lower_only) {
     return gemm_nt_launch_batched<T>(c, klass, m, n, k, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, D, ldd, 0,
-                                     lower_only, 1, 0, nullptr, nullptr, 0);
+                                     lower_only, 1, 0, nullptr, nullptr, 0, 0);
 }
 // D = alpha A B^T for ONE column tile (n = 128), and per output row the sums of d^2 and d * w[column] over the tile
 template <typename T>
 int gemm_nt_launch_stats(algp_ctx* c, int klass, int64_t m, int64_t k, T alpha, const T* A, int64_t lda, const T* B, int64_t ldb,
                          T* D, int64_t ldd, const T* w, T* stat_out, int64_t stat_ld) {
     return gemm_nt_launch_batched<T>(c, klass, m, 128, k, alpha, A, lda, 0, B, ldb, 0, (T)0, nullptr, 0, 0, D, ldd, 0, 0, 1, 0, w,
-                                     stat_out, stat_ld);
+                                     stat_out, stat_ld, 0);
 }
+// D (m x n) = A B^T with B (n x n) lower triangular by 128-tiles -- X_J = T inv(L_JJ)^T with the explicit inverse of a 512-column
+// block: column tile c walks k < 128 (c + 1) only; stat_out (or null): the row statistics of every column tile as above
+template <typename T>
+int gemm_nt_launch_tri(algp_ctx* c, int klass, int64_t m, int64_t n, const T* A, int64_t lda, const T* B, int64_t ldb, T* D,
+                       int64_t ldd, const T* w, T* stat_out, int64_t stat_ld) {
+    return gemm_nt_launch_batched<T>(c, klass, m, n, n, (T)1, A, lda, 0, B, ldb, 0, (T)0, nullptr, 0, 0, D, ldd, 0, 0, 1, 0,
+                                     stat_out ? w : nullptr, stat_out, stat_ld, 1);
+}
+template int gemm_nt_launch_tri<double>(algp_ctx*, int, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*,
+                                        int64_t, const double*, double*, int64_t);
+template int gemm_nt_launch_tri<float>(algp_ctx*, int, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t,
+                                       const float*, float*, int64_t);
 template int gemm_nt_launch_stats<double>(algp_ctx*, int, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t,
                                           double*, int64_t, const double*, double*, int64_t);
 template int gemm_nt_launch_stats<float>(algp_ctx*, int, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, float*,
@@ -369,10 +387,10 @@ template int gemm_nt_launch<float>(algp_ctx*, int, int64_t, int64_t, int64_t, fl
                                    const float*, int64_t, float, const float*, int64_t, float*, int64_t, int);
 template int gemm_nt_launch_batched<double>(algp_ctx*, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
                                             int64_t, const double*, int64_t, int64_t, double, const double*, int64_t,
-                                            int64_t, double*, int64_t, int64_t, int, int, int, const double*, double*, int64_t);
+                                            int64_t, double*, int64_t, int64_t, int, int, int, const double*, double*, int64_t, int);
 template int gemm_nt_launch_batched<float>(algp_ctx*, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
                                            int64_t, const float*, int64_t, int64_t, float, const float*, int64_t, int64_t,
-                                           float*, int64_t, int64_t, int, int, int, const float*, float*, int64_t);
+                                           float*, int64_t, int64_t, int, int, int, const float*, float*, int64_t, int);
 
 // ---------------------------------------------------------------------------------------------
 // MFMA fragment-layout probe (exact integer data, asymmetric B).

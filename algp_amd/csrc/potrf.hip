@@ -127,13 +127,90 @@ int cholesky_blocked(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, doubl
 template int cholesky_blocked<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*);
 template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*);
 
+// ---------------------------------------------------------------------------------------------
+// Explicit inverses of the factor's full 512 x 512 diagonal blocks (J >= 1), for the left-looking candidate solve: with
+// them the solve inside a block is ONE product, X_J = T_J inv(L_JJ)^T (gemm_nt_launch_tri), where the 128-column steps
+// were seven short launches of one column tile each (15 ms of 162 per config-4 solve for 5 % of its flops).  Built from
+// the 128-block inverses the factorisation leaves (invD) by two levels of recursive doubling,
+//     X_(hi,lo) = - X_hi ( L_(hi,lo) X_lo ),
+// every product as the library's NT GEMM, batched over the blocks: P^T = X_lo^T L_(hi,lo)^T needs X_lo transposed (a small
+// kernel), the second product takes P^T as its B operand as it is.  ~0.25 ms per solve at N = 10 000 (19 blocks).
+// Layout of `out`: block J - 1 at out + (J - 1) * 512 * 512, row-major, leading dimension 512, zeros above the diagonal.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_tiles_kernel(const T* src, int64_t lds_, int64_t sstride, T* dst, int64_t ldd,
+                                                              int64_t dstride) {
+    __shared__ T t[32][33];
+    const T* s = src + (int64_t)blockIdx.z * sstride;
+    T* d = dst + (int64_t)blockIdx.z * dstride;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[ty + 8 * i][tx] = s[(int64_t)(r0 + ty + 8 * i) * lds_ + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[(int64_t)(c0 + ty + 8 * i) * ldd + r0 + tx] = t[tx][ty + 8 * i];
+}
+// zero a block and put the four 128 x 128 diagonal inverses on its diagonal
+template <typename T>
+__global__ __launch_bounds__(256) void inv512_init_kernel(const T* invD4, T* out) {
+    const T* src = invD4 + (int64_t)blockIdx.y * 4 * NB * NB;
+    T* dst = out + (int64_t)blockIdx.y * WB * WB;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;     // element of the 512 x 512 block
+    const int r = (int)(e / WB), col = (int)(e % WB);
+    const int tr = r / NB, tc = col / NB;
+    dst[e] = tr == tc ? src[(int64_t)tr * NB * NB + (r % NB) * NB + (col % NB)] : (T)0;
+}
+template <typename T>
+static int build_inv512(algp_ctx* c, int klass, const T* L, int64_t ldl, const T* invD, int64_t npad, T* out, T* scr) {
+    const int nb = (int)(npad / WB) - 1;                           // full blocks J = 1 .. npad / 512 - 1
+    if (nb <= 0) return ALGP_OK;
+    const T* L1 = L + (int64_t)WB * ldl + WB;                       // block J = 1
+    const T* D1 = invD + (int64_t)4 * NB * NB;                      // its first 128-block inverse
+    const int64_t sL = (int64_t)WB * ldl + WB, sD = 4 * NB * NB, sO = (int64_t)WB * WB;
+    T* DT = scr;                                                    // [nb][4][128 x 128]: the diagonal inverses transposed
+    T* PT1 = DT + (int64_t)nb * 4 * NB * NB;                        // [nb][128 x 128]
+    T* XT = PT1 + (int64_t)nb * NB * NB;                            // [nb][256 x 256]
+    T* PT2 = XT + (int64_t)nb * 256 * 256;                          // [nb][256 x 256]
+    hipLaunchKernelGGL(inv512_init_kernel<T>, dim3(WB * WB / 256, (unsigned)nb), dim3(256), 0, c->cur, D1, out);
+    for (int t = 0; t < 4; ++t)
+        hipLaunchKernelGGL(transpose_tiles_kernel<T>, dim3(4, 4, (unsigned)nb), dim3(256), 0, c->cur, D1 + (int64_t)t * NB * NB, (int64_t)NB,
+                           sD, DT + (int64_t)t * NB * NB, (int64_t)NB, sD);
+    ALGP_HIP(hipGetLastError());
+    // level 1: tiles (1, 0) and (3, 2)
+    for (int lo = 0; lo < 4; lo += 2) {
+        const int hi = lo + 1;
+        ALGP_TRY(gemm_nt_launch_batched<T>(c, klass, NB, NB, NB, (T)1, DT + (int64_t)lo * NB * NB, NB, sD, L1 + (int64_t)(NB * hi) * ldl + NB * lo,
+                                           ldl, sL, (T)0, nullptr, 0, 0, PT1, NB, (int64_t)NB * NB, 0, nb));
+        ALGP_TRY(gemm_nt_launch_batched<T>(c, klass, NB, NB, NB, (T)-1, D1 + (int64_t)hi * NB * NB, NB, sD, PT1, NB, (int64_t)NB * NB, (T)0,
+                                           nullptr, 0, 0, out + (int64_t)(NB * hi) * WB + NB * lo, WB, sO, 0, nb));
+    }
+    // level 2: the 256 x 256 block (2..3, 0..1)
+    hipLaunchKernelGGL(transpose_tiles_kernel<T>, dim3(8, 8, (unsigned)nb), dim3(256), 0, c->cur, out, (int64_t)WB, sO, XT, (int64_t)256,
+                       (int64_t)256 * 256);
+    ALGP_HIP(hipGetLastError());
+    ALGP_TRY(gemm_nt_launch_batched<T>(c, klass, 256, 256, 256, (T)1, XT, 256, (int64_t)256 * 256, L1 + (int64_t)256 * ldl, ldl, sL, (T)0,
+                                       nullptr, 0, 0, PT2, 256, (int64_t)256 * 256, 0, nb));
+    ALGP_TRY(gemm_nt_launch_batched<T>(c, klass, 256, 256, 256, (T)-1, out + (int64_t)256 * WB + 256, WB, sO, PT2, 256, (int64_t)256 * 256, (T)0,
+                                       nullptr, 0, 0, out + (int64_t)256 * WB, WB, sO, 0, nb));
+    return ALGP_OK;
+}
+template <typename T>
+static size_t inv512_scratch_elems(int64_t npad) {
+    const int64_t nb = npad / WB - 1;
+    return nb <= 0 ? 0 : (size_t)nb * (4 * NB * NB + NB * NB + 2 * 256 * 256);
+}
+
 // X <- X L^-T, left-looking over 512-wide column blocks:
 //   X_J <- X_J - X_{0:J} L_{J,0:J}^T            (one GEMM, n = 512)
 //   inside J, 128 columns at a time: X_k <- (X_k - X_{J0:k} L_{k,J0:k}^T) inv(L_kk)^T
 template <typename T>
 static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                      int64_t ldl, const T* invD, int64_t col_start, bool whole_solve, const T* stat_w = nullptr,
-                     T* stat_out = nullptr, int64_t stat_ld = 0) {
+                     T* stat_out = nullptr, int64_t stat_ld = 0, const T* inv512 = nullptr, T* tmp512 = nullptr) {
+    // inv512 / tmp512 (left-looking order, col_start == 0): the explicit inverses of the full 512-column blocks J >= 1
+    // (build_inv512) and mpad x 512 scratch: block J is then two launches -- T = X_J - X_{0:J} L_{J,0:J}^T into the scratch,
+    // X_J = T inv(L_JJ)^T -- instead of eight.
     // stat_out (left-looking order only, col_start == 0: trsm_blocked decides): the launch that writes a column tile of X for
     // the last time also leaves the tile's row sums of x^2 and x * stat_w[column] at stat_out[(2 tile + 0 / 1) * stat_ld + row]
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
@@ -222,6 +299,12 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
         if (j0 + w <= col_start) continue;
         const int64_t cs = j0 > col_start ? j0 : col_start;         // first column of this block to solve
         T* Xj = X + j0;
+        if (inv512 && tmp512 && j0 > 0 && w == TWB && col_start == 0) {
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, TWB, j0, (T)-1, X, ldx, L + j0 * ldl, ldl, (T)1, Xj, ldx, tmp512, TWB, 0));
+            ALGP_TRY(gemm_nt_launch_tri<T>(c, klass, mpad, TWB, tmp512, TWB, inv512 + (j0 / TWB - 1) * TWB * TWB, TWB, Xj, ldx,
+                                           stat_w ? stat_w + j0 : nullptr, stat_out ? stat_out + 2 * (j0 / NB) * stat_ld : nullptr, stat_ld));
+            continue;
+        }
         if (j0 > 0)
             ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, j0 + w - cs, j0, (T)-1, X, ldx, L + cs * ldl, ldl, (T)1, X + cs,
                                        ldx, X + cs, ldx, 0));
@@ -294,8 +377,9 @@ template int trinv_upper<float>(algp_ctx*, int, float*, int64_t, int64_t, const 
 template <typename T>
 static int trsm_rows(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                      int64_t ldl, const T* invD, int64_t col_start, bool whole_solve, const T* stat_w = nullptr,
-                     T* stat_out = nullptr, int64_t stat_ld = 0) {
-    return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, whole_solve, stat_w, stat_out, stat_ld);
+                     T* stat_out = nullptr, int64_t stat_ld = 0, const T* inv512 = nullptr, T* tmp512 = nullptr) {
+    return trsm_rows_blocked<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, whole_solve, stat_w, stat_out, stat_ld, inv512,
+                                tmp512);
 }
 
 static hipEvent_t sync_event(algp_ctx* c, size_t i) {
@@ -319,12 +403,27 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
     const bool stats = stat_out && stat_w && col_start == 0 && tiles > TRSM_PUSH_TILES;
     if (stats_done) *stats_done = stats;
     if (!stats) stat_out = nullptr;
+    // the left-looking order from column 0 (the same condition): 512-block inverses, one scratch of mpad x 512 for all chunks
+    // ($ALGP_TRSM_INV512=0: the 128-column steps inside a block, as in rounds 1-3)
+    const T* inv512 = nullptr;
+    T* tmp512 = nullptr;
+    {
+        const bool on = !(getenv("ALGP_TRSM_INV512") && atoi(getenv("ALGP_TRSM_INV512")) == 0);      // read per call: tests flip it
+        if (on && col_start == 0 && tiles > TRSM_PUSH_TILES && npad / WB >= 2 && c->cur == c->stream &&
+            ensure(c, c->inv512, sizeof(T) * (size_t)(npad / WB - 1) * WB * WB) == ALGP_OK &&
+            ensure(c, c->inv512_scr, sizeof(T) * inv512_scratch_elems<T>(npad)) == ALGP_OK &&
+            ensure(c, c->trsm_tmp, sizeof(T) * (size_t)mpad * WB) == ALGP_OK) {
+            ALGP_TRY(build_inv512<T>(c, klass, L, ldl, invD, npad, (T*)c->inv512.p, (T*)c->inv512_scr.p));
+            inv512 = (const T*)c->inv512.p;
+            tmp512 = (T*)c->trsm_tmp.p;
+        }
+    }
     hipStream_t streams[4] = {c->stream, c->stream2, c->stream3, c->stream4};
     int nch = c->trsm_chunks < 1 ? 1 : (c->trsm_chunks > 4 ? 4 : c->trsm_chunks);
     while (nch > 1 && (!streams[nch - 1] || tiles < 32 * nch)) --nch;
     if (col_start == 0 && tiles <= TRSM_PUSH_TILES) nch = 1;    // the right-looking order fills the machine by itself
     if (nch == 1 || c->cur != c->stream)
-        return trsm_rows<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, true, stat_w, stat_out, stat_ld);
+        return trsm_rows<T>(c, klass, X, mpad, ldx, L, npad, ldl, invD, col_start, true, stat_w, stat_out, stat_ld, inv512, tmp512);
     ALGP_HIP(hipEventRecord(sync_event(c, 0), streams[0]));
     int rc = ALGP_OK;
     int64_t r0 = 0;
@@ -334,7 +433,7 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
         c->cur = streams[k];
         if (rc == ALGP_OK)
             rc = trsm_rows<T>(c, klass, X + r0 * ldx, rows, ldx, L, npad, ldl, invD, col_start, false, stat_w,
-                              stat_out ? stat_out + r0 : nullptr, stat_ld);
+                              stat_out ? stat_out + r0 : nullptr, stat_ld, inv512, tmp512 ? tmp512 + r0 * WB : nullptr);
         r0 += rows;
     }
     c->cur = streams[0];

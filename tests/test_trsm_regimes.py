@@ -101,6 +101,55 @@ def test_row_statistics_come_out_of_the_solves_own_launches(monkeypatch):
         c.close()
 
 
+def test_explicit_inverses_of_the_512_column_blocks(monkeypatch):
+    """The left-looking order solves inside a full 512-column block J >= 1 with ONE product against the block's explicit
+    inverse (potrf.hip: build_inv512 from the factorisation's 128-block inverses, gemm.hip: kcut) instead of seven
+    128-column launches ($ALGP_TRSM_INV512=0).  3 000 train rows = five full blocks + a ragged one: both ways against the
+    oracle (utils.py:293-319) and against each other, in both precisions; fewer launches with the inverses."""
+    global N
+    old_n = N
+    N = 3000
+    try:
+        for dtype, tol, loose in ((np.float64, 1e-9, 1e-10), (np.float32, 3e-3, 5e-4)):
+            rng = np.random.RandomState(12)
+            M = 51300
+            side = 60
+            xx, yy = np.meshgrid(np.arange(side), np.arange(side))
+            grid = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)
+            A = np.sort(rng.permutation(len(grid))[:N])
+            pool = np.vstack([grid, rng.uniform(0, side, (M, 2))])
+            var = rng.choice([0.01, 1.0], N)
+            y = rng.uniform(0, 1, N)
+            cidx = np.arange(len(grid), len(grid) + M)
+            c = _hip.Context(dtype)
+            c.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)
+            c.set_pool(pool)
+            c.set_train(A, y, var)
+            c.factorize()
+            c.set_candidates(cidx, prior_includes_noise=False)
+            samp = np.sort(rng.permutation(M)[:160])
+            ref = O.posterior_chol(HYP, pool[A], y, pool[cidx[samp]], var)
+            out, launches = [], []
+            c.prof_enable(True)
+            for flag in ('1', '0'):
+                monkeypatch.setenv('ALGP_TRSM_INV512', flag)
+                c.prof_reset()
+                c.solve_candidates()
+                launches.append(c.prof_get('gemm_trsm')['launches'])
+                mu, pv = c.posterior()
+                assert np.max(np.abs(mu[samp] - ref['mu'])) <= tol * max(1.0, np.max(np.abs(ref['mu']))), (dtype, flag)
+                assert np.max(np.abs(pv[samp] - ref['var'])) <= tol, (dtype, flag)
+                out.append((mu, pv))
+            monkeypatch.delenv('ALGP_TRSM_INV512')
+            c.prof_enable(False)
+            assert launches[0] < launches[1] - 30, launches
+            assert np.max(np.abs(out[0][0] - out[1][0])) <= loose * max(1.0, np.max(np.abs(out[1][0])))
+            assert np.max(np.abs(out[0][1] - out[1][1])) <= loose
+            c.close()
+    finally:
+        N = old_n
+
+
 def test_push_order_six_blocks_deep_against_the_oracle_and_one_stream(monkeypatch):
     """the right-looking order over 512-column blocks (potrf.hip; the fallback of the task-list solve for train
     sets beyond its range, selected here with ALGP_SOLVE_DAG=0) rotates four pairs of events between its two streams; with
