@@ -318,11 +318,11 @@ int gemm_nt_launch_batched(algp_ctx* c, int klass, int64_t m, int64_t n, int64_t
     const double bytes = sizeof(T) * batch * ((double)tiles * 128.0 * 128.0 * (beta != (T)0 ? 2.0 : 1.0) +
                                               (double)k * 128.0 * (double)(g.tiles_m + g.tiles_n));
     {
-        // $ALGP_LAUNCH_LOG=<file>: one line per GEMM launch, in enqueue order (class m n k lower_only batch ktri): joined with a
+        // $ALGP_LAUNCH_LOG=<file>: one line per GEMM launch, in enqueue order (class m n k lower_only batch ktri element-size kcut): joined with a
         // rocprofv3 kernel trace by dispatch order, it gives the trace the K its grid sizes do not show (tools/trace_shapes.py)
         static FILE* launch_log = getenv("ALGP_LAUNCH_LOG") ? fopen(getenv("ALGP_LAUNCH_LOG"), "w") : nullptr;
         if (launch_log) {
-            fprintf(launch_log, "%d %lld %lld %lld %d %d %d %d\n", klass, (long long)m, (long long)n, (long long)k, lower_only, batch, ktri, (int)sizeof(T));
+            fprintf(launch_log, "%d %lld %lld %lld %d %d %d %d %d\n", klass, (long long)m, (long long)n, (long long)k, lower_only, batch, ktri, (int)sizeof(T), kcut);
             fflush(launch_log);
         }
     }

@@ -17,7 +17,9 @@ if len(rows) != len(launches):
 shape = defaultdict(lambda: [0, 0.0, 0.0])
 tot_ns, tot_fl, n2 = 0, 0.0, 0
 first, last = None, None
-for r, (klass, m, n, k, lower, batch, ktri, es) in zip(rows, launches):
+for r, rec in zip(rows, launches):
+    klass, m, n, k, lower, batch, ktri, es = rec[:8]
+    kcut = rec[8] if len(rec) > 8 else 0
     tiles = int(r['Grid_Size_X']) // 256
     want = (m // 128) * (m // 128 + 1) // 2 if lower else (m // 128) * (n // 128)
     if not ktri and tiles != want:
@@ -26,7 +28,9 @@ for r, (klass, m, n, k, lower, batch, ktri, es) in zip(rows, launches):
         continue
     ns = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
     fl = 2.0 * 128 * 128 * k * tiles * batch
-    s = shape[(tiles, k)]
+    if kcut:                                   # column tile c of n / 128 walks k < 128 (c + 1) only (a block's explicit inverse)
+        fl *= (n // 128 + 1) / (2.0 * (n // 128))
+    s = shape[(tiles, -k if kcut else k)]
     s[0] += 1
     s[1] += ns * 1e-6
     s[2] += fl
@@ -36,7 +40,7 @@ for r, (klass, m, n, k, lower, batch, ktri, es) in zip(rows, launches):
 print('candidate-solve GEMM launches (class GEMM_TRSM): %d in %d solves' % (n2, nsolves))
 print('%10s %7s %7s %11s %10s' % ('tiles', 'K', 'calls', 'sum ms', 'TFLOP/s'))
 for (tiles, k), (calls, ms, fl) in sorted(shape.items(), key=lambda kv: -kv[1][1]):
-    print('%10d %7d %7d %11.3f %10.1f' % (tiles, k, calls, ms, fl / (ms * 1e-3) / 1e12))
+    print('%10d %7s %7d %11.3f %10.1f' % (tiles, ('<=%d' % -k) if k < 0 else str(k), calls, ms, fl / (ms * 1e-3) / 1e12))
 per = tot_ns * 1e-6 / nsolves
 print('sum of launch durations per solve: %.2f ms (%d launches per solve); executed flop per solve %.4g -> %.1f TFLOP/s executed'
       % (per, n2 // nsolves, tot_fl / nsolves, tot_fl / nsolves / (per * 1e-3) / 1e12))
