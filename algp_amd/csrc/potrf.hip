@@ -128,14 +128,14 @@ template int cholesky_blocked<double>(algp_ctx*, double*, int64_t, int64_t, doub
 template int cholesky_blocked<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*);
 
 // ---------------------------------------------------------------------------------------------
-// Explicit inverses of the factor's full 512 x 512 diagonal blocks (J >= 1), for the left-looking candidate solve: with
+// Explicit inverses of the factor's full 512 x 512 diagonal blocks, for the left-looking candidate solve: with
 // them the solve inside a block is ONE product, X_J = T_J inv(L_JJ)^T (gemm_nt_launch_tri), where the 128-column steps
 // were seven short launches of one column tile each (15 ms of 162 per config-4 solve for 5 % of its flops).  Built from
 // the 128-block inverses the factorisation leaves (invD) by two levels of recursive doubling,
 //     X_(hi,lo) = - X_hi ( L_(hi,lo) X_lo ),
 // every product as the library's NT GEMM, batched over the blocks: P^T = X_lo^T L_(hi,lo)^T needs X_lo transposed (a small
 // kernel), the second product takes P^T as its B operand as it is.  ~0.25 ms per solve at N = 10 000 (19 blocks).
-// Layout of `out`: block J - 1 at out + (J - 1) * 512 * 512, row-major, leading dimension 512, zeros above the diagonal.
+// Layout of `out`: block J at out + J * 512 * 512, row-major, leading dimension 512, zeros above the diagonal.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_tiles_kernel(const T* src, int64_t lds_, int64_t sstride, T* dst, int64_t ldd,
@@ -163,10 +163,10 @@ __global__ __launch_bounds__(256) void inv512_init_kernel(const T* invD4, T* out
 }
 template <typename T>
 static int build_inv512(algp_ctx* c, int klass, const T* L, int64_t ldl, const T* invD, int64_t npad, T* out, T* scr) {
-    const int nb = (int)(npad / WB) - 1;                           // full blocks J = 1 .. npad / 512 - 1
+    const int nb = (int)(npad / WB);                               // full blocks J = 0 .. npad / 512 - 1
     if (nb <= 0) return ALGP_OK;
-    const T* L1 = L + (int64_t)WB * ldl + WB;                       // block J = 1
-    const T* D1 = invD + (int64_t)4 * NB * NB;                      // its first 128-block inverse
+    const T* L1 = L;                                                // block J = 0
+    const T* D1 = invD;                                             // its first 128-block inverse
     const int64_t sL = (int64_t)WB * ldl + WB, sD = 4 * NB * NB, sO = (int64_t)WB * WB;
     T* DT = scr;                                                    // [nb][4][128 x 128]: the diagonal inverses transposed
     T* PT1 = DT + (int64_t)nb * 4 * NB * NB;                        // [nb][128 x 128]
@@ -197,7 +197,7 @@ static int build_inv512(algp_ctx* c, int klass, const T* L, int64_t ldl, const T
 }
 template <typename T>
 static size_t inv512_scratch_elems(int64_t npad) {
-    const int64_t nb = npad / WB - 1;
+    const int64_t nb = npad / WB;
     return nb <= 0 ? 0 : (size_t)nb * (4 * NB * NB + NB * NB + 2 * 256 * 256);
 }
 
@@ -208,9 +208,9 @@ template <typename T>
 static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t npad,
                      int64_t ldl, const T* invD, int64_t col_start, bool whole_solve, const T* stat_w = nullptr,
                      T* stat_out = nullptr, int64_t stat_ld = 0, const T* inv512 = nullptr, T* tmp512 = nullptr) {
-    // inv512 / tmp512 (left-looking order, col_start == 0): the explicit inverses of the full 512-column blocks J >= 1
-    // (build_inv512) and mpad x 512 scratch: block J is then two launches -- T = X_J - X_{0:J} L_{J,0:J}^T into the scratch,
-    // X_J = T inv(L_JJ)^T -- instead of eight.
+    // inv512 / tmp512 (left-looking order, col_start == 0): the explicit inverses of the full 512-column blocks
+    // (build_inv512) and mpad x 512 scratch, holding X_0 on entry: block J is then two launches -- T = X_J - X_{0:J} L_{J,0:J}^T
+    // into the scratch, X_J = T inv(L_JJ)^T -- instead of eight.
     // stat_out (left-looking order only, col_start == 0: trsm_blocked decides): the launch that writes a column tile of X for
     // the last time also leaves the tile's row sums of x^2 and x * stat_w[column] at stat_out[(2 tile + 0 / 1) * stat_ld + row]
     // col_start (multiple of 128): columns [0, col_start) of X already hold the solution
@@ -299,9 +299,10 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
         if (j0 + w <= col_start) continue;
         const int64_t cs = j0 > col_start ? j0 : col_start;         // first column of this block to solve
         T* Xj = X + j0;
-        if (inv512 && tmp512 && j0 > 0 && w == TWB && col_start == 0) {
-            ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, TWB, j0, (T)-1, X, ldx, L + j0 * ldl, ldl, (T)1, Xj, ldx, tmp512, TWB, 0));
-            ALGP_TRY(gemm_nt_launch_tri<T>(c, klass, mpad, TWB, tmp512, TWB, inv512 + (j0 / TWB - 1) * TWB * TWB, TWB, Xj, ldx,
+        if (inv512 && tmp512 && w == TWB && col_start == 0) {
+            // (block 0 has nothing to its left: the caller has copied its right-hand sides into the scratch)
+            if (j0 > 0) ALGP_TRY(gemm_nt_launch<T>(c, klass, mpad, TWB, j0, (T)-1, X, ldx, L + j0 * ldl, ldl, (T)1, Xj, ldx, tmp512, TWB, 0));
+            ALGP_TRY(gemm_nt_launch_tri<T>(c, klass, mpad, TWB, tmp512, TWB, inv512 + (j0 / TWB) * TWB * TWB, TWB, Xj, ldx,
                                            stat_w ? stat_w + j0 : nullptr, stat_out ? stat_out + 2 * (j0 / NB) * stat_ld : nullptr, stat_ld));
             continue;
         }
@@ -409,13 +410,16 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
     T* tmp512 = nullptr;
     {
         const bool on = !(getenv("ALGP_TRSM_INV512") && atoi(getenv("ALGP_TRSM_INV512")) == 0);      // read per call: tests flip it
-        if (on && col_start == 0 && tiles > TRSM_PUSH_TILES && npad / WB >= 2 && c->cur == c->stream &&
-            ensure(c, c->inv512, sizeof(T) * (size_t)(npad / WB - 1) * WB * WB) == ALGP_OK &&
+        if (on && col_start == 0 && tiles > TRSM_PUSH_TILES && npad / WB >= 1 && c->cur == c->stream &&
+            ensure(c, c->inv512, sizeof(T) * (size_t)(npad / WB) * WB * WB) == ALGP_OK &&
             ensure(c, c->inv512_scr, sizeof(T) * inv512_scratch_elems<T>(npad)) == ALGP_OK &&
             ensure(c, c->trsm_tmp, sizeof(T) * (size_t)mpad * WB) == ALGP_OK) {
             ALGP_TRY(build_inv512<T>(c, klass, L, ldl, invD, npad, (T*)c->inv512.p, (T*)c->inv512_scr.p));
             inv512 = (const T*)c->inv512.p;
             tmp512 = (T*)c->trsm_tmp.p;
+            // block 0's right-hand sides into the scratch: its product with inv(L_00)^T cannot run in place (a workgroup
+            // of column tile c reads the tiles left of it in the same rows)
+            ALGP_HIP(hipMemcpy2DAsync(tmp512, sizeof(T) * WB, X, sizeof(T) * ldx, sizeof(T) * WB, (size_t)mpad, hipMemcpyDeviceToDevice, c->cur));
         }
     }
     hipStream_t streams[4] = {c->stream, c->stream2, c->stream3, c->stream4};
