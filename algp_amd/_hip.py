@@ -89,6 +89,7 @@ SIGNATURES = {
     'algp_comm_init': (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_void_p]),
     'algp_comm_init_host': (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'algp_comm_destroy': (C.c_int, [_c_ctx]),
+    'algp_comm_set_owners': (C.c_int, [_c_ctx, C.POINTER(C.c_int32), C.c_int64]),
     'algp_debug_first_max': (C.c_int, [_c_ctx, _dblp, C.c_int, _dblp]),
     'algp_debug_fail_next_pick': (C.c_int, [_c_ctx, C.c_int]),
     'algp_debug_set_trsm_chunks': (C.c_int, [_c_ctx, C.c_int]),
@@ -439,6 +440,21 @@ class Context(object):
         self._check(self.lib.algp_comm_destroy(self.h))
         self._gather_cb = None
 
+    def comm_set_owners(self, owner):
+        """owner[q] = rank that holds pool site q as a candidate (-1: nobody), the same array on every rank; None clears
+        it.  With a map attached factorize(incremental=True) is a collective: the rows of L of the new train sites travel
+        from their owners' V^T in one all-gather instead of being solved on every rank (algp_comm_set_owners)."""
+        if owner is None:
+            self._check(self.lib.algp_comm_set_owners(self.h, None, 0))
+            return
+        o = np.ascontiguousarray(owner, dtype=np.int32).reshape(-1)
+        self._check(self.lib.algp_comm_set_owners(self.h, o.ctypes.data_as(C.POINTER(C.c_int32)), len(o)))
+
+    def counter(self, which):
+        """algp_debug_counter: 0 stream synchronisations so far | 1 rows of L the last factor update placed without a
+        triangular solve | 2 how many of them arrived from other ranks | 3 row exchanges so far | 4 agreed fall-backs."""
+        return int(self.lib.algp_debug_counter(self.h, int(which)))
+
     def debug_first_max(self, triples):
         """first_max_kernel on a fabricated (nranks, 3) buffer -> (utility, pool index, owner, status, failing rank)."""
         t = np.ascontiguousarray(triples, dtype=np.float64).reshape(-1, 3)
@@ -455,7 +471,7 @@ class Context(object):
 
     def debug_fail_at(self, where, code):
         """Inject `code` into this rank's next greedy pick: where = 0 resolving its best, 1 committing the winner (after the
-        exchange), 2 packing its contribution (algp_debug_fail_at)."""
+        exchange), 2 packing its contribution, 3 the agreement word of its next sharded factor update (algp_debug_fail_at)."""
         self._check(self.lib.algp_debug_fail_at(self.h, int(where), int(code)))
 
     def debug_trsv_stall(self, block):

@@ -36,8 +36,13 @@ def get_heading(prev, cur):
 
 
 class Agent(object):
-    def __init__(self, env, args, parent_agent=None, learn_likelihood_noise=True, mobile_std=None, static_std=None):
+    def __init__(self, env, args, parent_agent=None, learn_likelihood_noise=True, mobile_std=None, static_std=None,
+                 comm=None):
+        """comm (not in the reference): a `sharded.ShardLink` -- this process is one rank of a job that shards the
+        candidates of `greedy` over several GPUs; every rank constructs the same agent on the same environment and
+        calls the same methods (the library's collectives sit inside greedy and the factor updates)."""
         self.env = env
+        self.comm = comm if (comm is not None and comm.world_size > 1) else None
         self.learn_likelihood_noise = learn_likelihood_noise
         self._init_model(args)
         self.static_std = args.static_std if static_std is None else static_std
@@ -207,6 +212,10 @@ class Agent(object):
             self._pool_key = key
             c._pool_owner = self
             self._pool_generation = c.pool_generation
+            self._comm_pool = None
+        if self.comm is not None and getattr(self, '_comm_pool', None) != (id(c), c.pool_generation):
+            self.comm.attach(c, self.env.num_samples)                # transport + owner map follow the pool
+            self._comm_pool = (id(c), c.pool_generation)
         return c
 
     # ---- planning steps ---------------------------------------------------------------------------
@@ -263,7 +272,8 @@ class Agent(object):
         shared = False
         if (len(A) and self._pool_key == ('x', id(self.env.X)) and getattr(g, '_pool_owner', None) is self
                 and g.pool_generation == getattr(self, '_pool_generation', -1)
-                and not self.gp.sync_hypers() and getattr(g, 'M', 0) == n):
+                and not self.gp.sync_hypers()
+                and getattr(g, 'M', 0) == (n if self.comm is None else len(self._shard()))):
             try:
                 if rows:
                     g.set_train(A, np.zeros(len(A)), tv)
@@ -359,25 +369,39 @@ class Agent(object):
         c = self._load_pool()
         static, mobile = self._masks()
         sampled = static | mobile
+        # sharded: this rank scores its share of the pool (the factor is replicated); one all-gather per pick inside
+        # algp_greedy_sharded, and the factor update below takes the new sites' rows from their owners' V^T
+        cand = np.arange(self.env.num_samples) if self.comm is None else self._shard()
         if self._use_rows():
             A, is_static = self._train_rows(static, mobile)
             c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))
             c.factorize(incremental=True)
-            c.set_candidates(np.arange(self.env.num_samples), prior_includes_noise=True)
-            c.solve_candidates(incremental=True, alive=~static)
+            c.set_candidates(cand, prior_includes_noise=True)
+            c.solve_candidates(incremental=True, alive=~static[cand])
         elif getattr(self, 'incremental', False):
             A = self._train_order(sampled)
             c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
             c.factorize(incremental=True)
-            c.set_candidates(np.arange(self.env.num_samples), prior_includes_noise=True)
-            c.solve_candidates(incremental=True, alive=~static)
+            c.set_candidates(cand, prior_includes_noise=True)
+            c.solve_candidates(incremental=True, alive=~static[cand])
         else:
             A = np.where(sampled)[0]
             c.set_train(A, np.zeros(len(A)), self._fused_var(static[A], mobile[A]))
-            c.set_candidates(np.where(~static)[0], prior_includes_noise=True)
+            c.set_candidates(cand[~static[cand]], prior_includes_noise=True)
             c.fit_and_solve()                                   # one task-list launch up to 51 200 candidates
-        picks = c.greedy(_CRIT[self.criterion], self.static_std, self.mobile_std, int(num_samples))
+        if self.comm is not None:
+            if self.criterion != 'entropy':
+                raise ValueError('only the entropy criterion shards (the MI criterion needs the pool-wide complement on one GPU)')
+            picks = c.greedy_sharded(_CRIT[self.criterion], self.static_std, self.mobile_std, int(num_samples))
+        else:
+            picks = c.greedy(_CRIT[self.criterion], self.static_std, self.mobile_std, int(num_samples))
         return [int(p) for p in picks]
+
+    def _shard(self):
+        key = (self.env.num_samples, self.comm.rank, self.comm.world_size, self.comm.layout)
+        if getattr(self, '_shard_key', None) != key:
+            self._shard_key, self._shard_idx = key, self.comm.mine(self.env.num_samples)
+        return self._shard_idx
 
     def best_path(self, paths_mobile_indices, static_indices):
         """Index of the most informative path (agent.py:358-403)."""
@@ -426,6 +450,9 @@ class Agent(object):
         n = self.env.num_samples
         pen = CONST + 0.5 * np.log(self.static_std ** 2 + self.mobile_std ** 2)     # per site that gets a second row
         clean = [[int(j) for j in dict.fromkeys(int(v) for v in path) if j != -1 and not mobile0[j]] for path in paths]
+        if self.comm is not None:
+            batched = False          # a shard does not hold every path site's row of V^T: the per-path factor updates run
+                                     # on every rank alike (replicated factor; their new rows come through the row exchange)
         if batched and max((len(p) for p in clean), default=0) <= 64:
             A, is_static = self._train_rows(static, mobile0)
             c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))

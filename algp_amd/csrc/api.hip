@@ -462,6 +462,136 @@ struct Impl {
         return true;
     }
 
+    // The same rows when the candidates are sharded over ranks (a communicator and an owner map are attached): every new
+    // train site is a candidate of exactly one rank, whose row of V^T (for a further reading of a site that is train row
+    // k already: L[k, :] - var_k * its unit row) is what EVERY rank's replica of the factor needs.  All ranks hold the
+    // same train set and owner map, so all compute the same plan -- owner and slot of every new row, cap = the largest
+    // count any rank contributes -- and take part in: a 32-byte agreement (comm_agree), then one all-gather of cap rows
+    // of Nb elements per rank.  *placed = 1: rows [p0, Npad) of L, columns [0, Nb), are in place; 0: the ranks agreed to
+    // solve them against the kept factor instead (some rank's V^T cannot supply its rows).  An error code >= 2 of any
+    // rank (an allocation that failed, ...) is returned by every rank.  Reference: agent.py:66-82 (the sites a step adds),
+    // agent.py:313-354 (the loop whose shards own them).
+    static int exchange_new_rows(algp_ctx* c, int64_t Nb, int64_t p0, int* placed) {
+        const int64_t N = c->N, Npad = c->Npad, ld = c->Lld;
+        const int nr = c->comm_nranks, me = c->comm_rank;
+        const int64_t nnew = N - p0, ntot = Npad - p0;
+        *placed = 0;
+        std::vector<int> owner((size_t)std::max<int64_t>(nnew, 0)), slot((size_t)std::max<int64_t>(nnew, 0));
+        std::vector<int64_t> cnt((size_t)nr, 0);
+        int st = 0;
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+        mix((uint64_t)Nb);
+        for (int64_t i = 0; i < nnew; ++i) {
+            const int64_t q = c->train_idx[(size_t)(p0 + i)];
+            const int o = c->site_owner[(size_t)q];
+            mix((uint64_t)q);
+            mix((uint64_t)(int64_t)o);
+            if (o < 0 || o >= nr) { st = 1; owner[(size_t)i] = -1; continue; }     // nobody holds this site as a candidate
+            owner[(size_t)i] = o;
+            slot[(size_t)i] = (int)cnt[(size_t)o]++;
+        }
+        int64_t cap = 0;
+        for (int r = 0; r < nr; ++r) cap = std::max(cap, cnt[(size_t)r]);
+        // this rank's own rows: the checks of vt_rows_for_new_sites, for the sites it owns
+        std::vector<int64_t> src_row((size_t)std::max<int64_t>(cap, 1), -1), lrow((size_t)std::max<int64_t>(cap, 1), -1);
+        std::vector<T> lscale((size_t)std::max<int64_t>(cap, 1), (T)0);
+        bool second = false;
+        if (st == 0 && cnt[(size_t)me] > 0) {
+            bool ok = c->Vt.p && c->vt_hyp_stamp == c->hyp_stamp && (int64_t)c->vt_fact_idx.size() >= Nb &&
+                      c->vt_cand_idx == c->cand_idx && (int64_t)c->vt_kind.size() == c->M;
+            for (int64_t r = 0; ok && r < Nb; ++r)
+                ok = c->vt_fact_idx[(size_t)r] == c->train_idx[(size_t)r] && c->vt_fact_var[(size_t)r] == c->train_var_host[(size_t)r];
+            for (int64_t i = 0; ok && i < nnew; ++i) {
+                if (owner[(size_t)i] != me) continue;
+                const int64_t q = c->train_idx[(size_t)(p0 + i)], j = c->cand_pos[(size_t)q];
+                if (j < 0) { ok = false; break; }                            // the map says this rank, its candidate list does not
+                const int k = c->vt_kind[(size_t)j];
+                if (k >= 0) {
+                    if (k >= p0 || c->train_idx[(size_t)k] != q || (int64_t)c->vt_fact_idx.size() <= k ||
+                        c->vt_fact_idx[(size_t)k] != q || c->vt_fact_var[(size_t)k] != c->train_var_host[(size_t)k]) { ok = false; break; }
+                    lrow[(size_t)slot[(size_t)i]] = k;
+                    lscale[(size_t)slot[(size_t)i]] = (T)c->train_var_host[(size_t)k];
+                    second = true;
+                }
+                src_row[(size_t)slot[(size_t)i]] = j;
+            }
+            if (!ok) st = 1;
+        }
+        const size_t rowbytes = sizeof(T) * (size_t)Nb;
+        // sized by the factor's capacity, not by this step's Nb and cap: the buffers then stay put while the train set grows
+        if (st <= 1 && cap > 0) {
+            const int rc = comm_rows_reserve(c, sizeof(T) * (size_t)c->Lld * (size_t)round_up(cap, 8));
+            if (rc != ALGP_OK) st = rc;
+        }
+        if (st <= 1) {
+            int rc = ensure(c, c->auxIdx, sizeof(int64_t) * 2 * (size_t)std::max<int64_t>(std::max(ntot, cap), 1));
+            if (rc == ALGP_OK) rc = ensure(c, c->auxVar, sizeof(T) * (size_t)std::max<int64_t>(cap, 1) + 256);
+            if (rc != ALGP_OK) st = rc;
+        }
+        if (c->debug_fail_next_rowx) {
+            st = c->debug_fail_next_rowx;
+            c->debug_fail_next_rowx = 0;
+            c->err = "factorize_update: failure injected by algp_debug_fail_at";
+        }
+        const std::string local_err = c->err;
+        double mine[4] = {(double)st, (double)p0, (double)N, 0.0};
+        memcpy(&mine[3], &h, sizeof(h));
+        std::vector<double> all;
+        ALGP_TRY(comm_agree(c, mine, all));
+        int worst = 0, bad_rank = -1;
+        bool same = true;
+        for (int r = 0; r < nr; ++r) {
+            const double* t = &all[(size_t)r * 4];
+            const int s_r = (t[0] == t[0] && t[0] >= 0 && t[0] <= 64) ? (int)t[0] : ALGP_ERR_HIP;
+            if (s_r > worst) { worst = s_r; bad_rank = r; }
+            if (t[1] != mine[1] || t[2] != mine[2] || memcmp(&t[3], &mine[3], 8) != 0) same = false;
+        }
+        if (worst >= 2) {
+            if (st >= 2) return fail(c, st, local_err);
+            return fail(c, worst, "factorize_update: rank " + std::to_string(bad_rank) + " failed with error " + std::to_string(worst) +
+                                      " before the row exchange; no rank updated its factor");
+        }
+        if (worst == 1 || !same) {
+            c->row_fallbacks += 1;
+            return ALGP_OK;                                                  // every rank solves the rows itself
+        }
+        if (cap > 0) {
+            T* own = (T*)c->rowx.p;
+            const size_t bytes = rowbytes * (size_t)cap;
+            T* gathered = (T*)((char*)c->rowx.p + bytes);
+            int64_t* d_src = (int64_t*)c->auxIdx.p;
+            int64_t* d_lrow = d_src + std::max<int64_t>(std::max(ntot, cap), 1);
+            ALGP_HIP(hipMemcpyAsync(d_src, src_row.data(), sizeof(int64_t) * (size_t)cap, hipMemcpyHostToDevice, c->stream));
+            if (second) {
+                ALGP_HIP(hipMemcpyAsync(d_lrow, lrow.data(), sizeof(int64_t) * (size_t)cap, hipMemcpyHostToDevice, c->stream));
+                ALGP_HIP(hipMemcpyAsync(c->auxVar.p, lscale.data(), sizeof(T) * (size_t)cap, hipMemcpyHostToDevice, c->stream));
+            }
+            // slots this rank does not fill (it owns fewer than cap rows) are written as zeros: src_row = -1
+            ALGP_TRY(gather_rows_launch<T>(c, p(c->Vt), c->ldv, d_src, own, Nb, cap, Nb, second ? d_lrow : nullptr,
+                                           second ? (const T*)c->auxVar.p : nullptr, p(c->L), ld));
+            ALGP_TRY(sync(c));                                               // src_row / lrow / lscale are host temporaries
+            ALGP_TRY(comm_rows_gather(c, bytes));
+            // scatter: factor row p0 + i <- the slot of its owner's contribution; padding rows are zero
+            std::vector<int64_t> from((size_t)ntot, -1);
+            int64_t peers = 0;
+            for (int64_t i = 0; i < nnew; ++i) {
+                from[(size_t)i] = (int64_t)owner[(size_t)i] * cap + slot[(size_t)i];
+                peers += owner[(size_t)i] != me;
+            }
+            ALGP_HIP(hipMemcpyAsync(d_src, from.data(), sizeof(int64_t) * (size_t)ntot, hipMemcpyHostToDevice, c->stream));
+            ALGP_TRY(gather_rows_launch<T>(c, gathered, Nb, d_src, p(c->L) + p0 * ld, ld, ntot, Nb));
+            ALGP_TRY(sync(c));
+            c->rows_from_peers = peers;
+            c->row_exchanges += 1;
+        } else if (ntot > 0) {
+            ALGP_HIP(hipMemset2DAsync(p(c->L) + p0 * ld, sizeof(T) * (size_t)ld, 0, rowbytes, (size_t)ntot, c->stream));
+            c->rows_from_peers = 0;
+        }
+        *placed = 1;
+        return ALGP_OK;
+    }
+
     static int factorize(algp_ctx* c, int incremental, Panel* panel = nullptr) {
         const int64_t N = c->N, Npad = c->Npad;
         int64_t keep = 0, p0 = 0;                                // rows of the resident factor to keep; unchanged leading rows
@@ -497,7 +627,20 @@ struct Impl {
             std::vector<int64_t> src_row, lrow;
             std::vector<T> lscale;
             bool second = false;
-            if (vt_rows_for_new_sites(c, Nb, p0, src_row, lrow, lscale, second)) {
+            // candidates sharded over ranks: the rows come from their owners (one exchange); this call is then a COLLECTIVE
+            const bool sharded = (c->comm || c->host_gather) && c->comm_nranks > 1 && !c->site_owner.empty() &&
+                                 (int64_t)c->site_owner.size() == c->n_pool;
+            int placed = 0;
+            c->rows_from_peers = 0;
+            if (sharded) {
+                frc = exchange_new_rows(c, Nb, p0, &placed);
+                if (frc != ALGP_OK) { prof_span_end(c); return frc; }
+            }
+            if (placed) {
+                frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p + Nb, N - Nb, R, (const int64_t*)c->Aidx.p + Nb, N - Nb, R,
+                                     (const T*)c->varA.p + Nb, c->pool_is_cov ? 0 : 1, nullptr, 1, rows + Nb, ld);
+                c->factor_rows_from_vt = Npad - p0;
+            } else if (!sharded && vt_rows_for_new_sites(c, Nb, p0, src_row, lrow, lscale, second)) {
                 frc = kmat_launch<T>(c, s, (const int64_t*)c->Aidx.p + Nb, N - Nb, R, (const int64_t*)c->Aidx.p + Nb, N - Nb, R,
                                      (const T*)c->varA.p + Nb, c->pool_is_cov ? 0 : 1, nullptr, 1, rows + Nb, ld);
                 const size_t nr = src_row.size();
@@ -1761,7 +1904,7 @@ void algp_destroy(algp_ctx* c) {
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
                       &c->lrow, &c->remote, &c->commbuf, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->rowstat, &c->inv512, &c->inv512_scr, &c->trsm_tmp, &c->splitk, &c->dag_state, &c->dag_stats, &c->trsv_ctrl, &c->miXbar, &c->miXall, &c->miDP, &c->miDQ, &c->miPos, &c->miU, &c->miW, &c->miCol, &c->miH, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
-                      &c->auxVar, &c->auxD, &c->hostStage};
+                      &c->auxVar, &c->auxD, &c->hostStage, &c->rowx};
     for (DevBuf* b : bufs) release(c, *b);
     dag_release(c);
     comm_destroy(c);
@@ -2013,7 +2156,24 @@ int algp_debug_first_max(algp_ctx* c, const double* triples, int nranks, double 
 }
 int64_t algp_debug_counter(algp_ctx* c, int which) {
     if (!c) return -1;
-    return which == 0 ? c->n_syncs : -1;
+    switch (which) {
+        case 0: return c->n_syncs;
+        case 1: return c->factor_rows_from_vt;
+        case 2: return c->rows_from_peers;
+        case 3: return c->row_exchanges;
+        case 4: return c->row_fallbacks;
+        default: return -1;
+    }
+}
+int algp_comm_set_owners(algp_ctx* c, const int32_t* owner, int64_t n_pool) {
+    CHECK_CTX(c);
+    if (!owner) { c->site_owner.clear(); return ALGP_OK; }
+    if (!c->comm && !c->host_gather) return fail(c, ALGP_ERR_STATE, "comm_set_owners: call algp_comm_init (or algp_comm_init_host) first");
+    if (n_pool != c->n_pool || n_pool <= 0) return fail(c, ALGP_ERR_BAD_ARG, "comm_set_owners: one entry per pool site (set the pool first)");
+    for (int64_t i = 0; i < n_pool; ++i)
+        if (owner[i] < -1 || owner[i] >= c->comm_nranks) return fail(c, ALGP_ERR_BAD_ARG, "comm_set_owners: rank outside the communicator");
+    c->site_owner.assign(owner, owner + n_pool);
+    return ALGP_OK;
 }
 int algp_debug_set_trsm_chunks(algp_ctx* c, int chunks) {
     CHECK_CTX(c);
@@ -2066,7 +2226,8 @@ int algp_debug_fail_at(algp_ctx* c, int where, int code) {
     if (where == 0) c->debug_fail_next_pick = code;
     else if (where == 1) c->debug_fail_next_commit = code;
     else if (where == 2) c->debug_fail_next_pack = code;
-    else return fail(c, ALGP_ERR_BAD_ARG, "debug_fail_at: where = 0 (pick), 1 (commit), 2 (pack)");
+    else if (where == 3) c->debug_fail_next_rowx = code;
+    else return fail(c, ALGP_ERR_BAD_ARG, "debug_fail_at: where = 0 (pick), 1 (commit), 2 (pack), 3 (row exchange)");
     return ALGP_OK;
 }
 int algp_comm_destroy(algp_ctx* c) {

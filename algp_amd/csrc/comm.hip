@@ -126,7 +126,10 @@ __global__ void first_max_kernel(const char* payloads, int64_t stride, int nrank
             if (bad < 0.0) bad = (double)r;
             if (!(s <= st)) st = s;                     // a NaN status counts as a failure too
         }
-        if (i >= 0.0 && v == v && (bi < 0.0 || v > bv)) { bv = v; bi = i; br = (double)r; }
+        // equal utilities: the smaller pool index, whichever rank offers it -- with contiguous shards in rank order that IS
+        // the first rank; with any other owner map (algp_comm_set_owners: e.g. site q on rank q mod n) it keeps the pick
+        // equal to np.argmax over the candidates in pool order
+        if (i >= 0.0 && v == v && (bi < 0.0 || v > bv || (v == bv && i < bi))) { bv = v; bi = i; br = (double)r; }
     }
     out[0] = bv;
     out[1] = bi;
@@ -220,6 +223,10 @@ void comm_destroy(algp_ctx* c) {
     if (c->comm_host) hipHostFree(c->comm_host);
     c->comm_host = nullptr;
     c->comm_host_cap = 0;
+    if (c->rowx_host) hipHostFree(c->rowx_host);
+    c->rowx_host = nullptr;
+    c->rowx_host_cap = 0;
+    c->site_owner.clear();
     c->comm = nullptr;
     c->host_gather = nullptr;
     c->host_gather_user = nullptr;
@@ -308,6 +315,79 @@ int comm_pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_de
                        const int* fresh_dev, int npicks, int status, double* rec5, const char** winner_payload) {
     return c->dtype == ALGP_F64 ? pick_exchange<double>(c, val_dev, pos_dev, cidx_dev, fresh_dev, npicks, status, rec5, winner_payload)
                                 : pick_exchange<float>(c, val_dev, pos_dev, cidx_dev, fresh_dev, npicks, status, rec5, winner_payload);
+}
+
+// ---- the factor update's row exchange (api.hip: exchange_new_rows) ------------------------------------------------------
+// The active-learning loop on sharded candidates (agent.py:125-229 with the loop of agent.py:313-354 cut into shards): the
+// sites a planning step adds to the train set -- the picks and the mobile readings along the chosen path, agent.py:66-82 --
+// are candidates of exactly one rank each, and that rank's row of V^T IS the site's new row of the replicated factor left
+// of the tail block.  Two collectives per factor update: a 32-byte agreement word per rank (status, first changed row, train
+// size, a hash of the plan -- so that every rank takes the same branch, and a rank that cannot take part says so instead
+// of leaving its peers in the second collective), then ONE all-gather of the rows (`cap` rows per rank, cap = the largest
+// number any rank owns; the plan is computed identically everywhere from the train set and the owner map).
+int comm_agree(algp_ctx* c, const double mine[4], std::vector<double>& all) {
+    const int nr = c->comm_nranks;
+    all.assign((size_t)nr * 4, 0.0);
+    if (c->host_gather) {
+        std::vector<double> send(mine, mine + 4);
+        const int rc = c->host_gather(c->host_gather_user, send.data(), all.data(), 32);
+        if (rc != 0) return fail(c, ALGP_ERR_HIP, "factorize_update: the caller's all-gather returned " + std::to_string(rc));
+        return ALGP_OK;
+    }
+    if (!c->comm) return fail(c, ALGP_ERR_STATE, "factorize_update: no communicator");
+    RcclApi* api = rccl_api(nullptr);
+    if (!api) return fail(c, ALGP_ERR_STATE, "factorize_update: the RCCL communicator has no library behind it");
+    ALGP_TRY(ensure(c, c->commbuf, std::max<size_t>(c->commbuf.cap, 32 * (size_t)(nr + 1))));
+    char* own = (char*)c->commbuf.p;
+    ALGP_HIP(hipMemcpyAsync(own, mine, 32, hipMemcpyHostToDevice, c->stream));
+    const ncclResult_t r = api->AllGather(own, own + 32, 32, ncclChar, (ncclComm_t)c->comm, c->stream);
+    if (r != ncclSuccess)
+        return fail(c, ALGP_ERR_HIP, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(r) : "failed"));
+    ALGP_HIP(hipMemcpyAsync(all.data(), own + 32, 32 * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+    ALGP_HIP(hipStreamSynchronize(c->stream));
+    c->n_syncs++;
+    return ALGP_OK;
+}
+// room for [own rows | every rank's rows] on the device (and in pinned memory for the host transport); grows geometrically
+int comm_rows_reserve(algp_ctx* c, size_t bytes_per_rank) {
+    const size_t need = bytes_per_rank * (size_t)(c->comm_nranks + 1);
+    if (!c->rowx.p || c->rowx.cap < need) ALGP_TRY(ensure(c, c->rowx, need + need / 4));
+    if (c->host_gather && c->rowx_host_cap < need) {
+        if (c->rowx_host) hipHostFree(c->rowx_host);
+        c->rowx_host = nullptr;
+        c->rowx_host_cap = 0;
+        const size_t want = need + need / 4;
+        if (hipHostMalloc(&c->rowx_host, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, ALGP_ERR_OOM, "comm: hipHostMalloc(" + std::to_string(want) + ") for the row exchange's staging failed");
+        }
+        c->rowx_host_cap = want;
+    }
+    return ALGP_OK;
+}
+// rowx[0 : bytes) of every rank -> rowx[bytes : bytes * (nranks + 1)) in rank order, stream-ordered on c->stream
+int comm_rows_gather(algp_ctx* c, size_t bytes_per_rank) {
+    const int nr = c->comm_nranks;
+    char* own = (char*)c->rowx.p;
+    char* all = own + bytes_per_rank;
+    if (c->comm) {
+        RcclApi* api = rccl_api(nullptr);
+        if (!api) return fail(c, ALGP_ERR_STATE, "factorize_update: the RCCL communicator has no library behind it");
+        const ncclResult_t r = api->AllGather(own, all, bytes_per_rank, ncclChar, (ncclComm_t)c->comm, c->stream);
+        if (r != ncclSuccess)
+            return fail(c, ALGP_ERR_HIP, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(r) : "failed"));
+        return ALGP_OK;
+    }
+    if (!c->host_gather) return fail(c, ALGP_ERR_STATE, "factorize_update: no communicator");
+    char* hs = (char*)c->rowx_host;
+    char* hr = hs + bytes_per_rank;
+    ALGP_HIP(hipMemcpyAsync(hs, own, bytes_per_rank, hipMemcpyDeviceToHost, c->stream));
+    ALGP_HIP(hipStreamSynchronize(c->stream));
+    c->n_syncs++;
+    const int rc = c->host_gather(c->host_gather_user, hs, hr, (int64_t)bytes_per_rank);
+    if (rc != 0) return fail(c, ALGP_ERR_HIP, "factorize_update: the caller's all-gather returned " + std::to_string(rc));
+    ALGP_HIP(hipMemcpyAsync(all, hr, bytes_per_rank * (size_t)nr, hipMemcpyHostToDevice, c->stream));
+    return ALGP_OK;
 }
 
 // test hook: first_max_kernel over a caller-made buffer of `nranks` triples (fabricated 8-rank cases on one GPU)

@@ -210,6 +210,15 @@ struct algp_ctx {
     algp::DevBuf commbuf;    // [own payload | gathered payloads | winner record], see comm.hip
     void* comm_host = nullptr;           // pinned staging of the host transport: [own payload | gathered payloads]
     size_t comm_host_cap = 0;
+    // the factor update's row exchange (comm.hip, api.hip: exchange_new_rows): which rank holds each pool site as a candidate
+    // (algp_comm_set_owners; empty: no exchange), [own rows | gathered rows] on the device, pinned staging (host transport)
+    std::vector<int32_t> site_owner;
+    algp::DevBuf rowx;
+    void* rowx_host = nullptr;
+    size_t rowx_host_cap = 0;
+    int64_t rows_from_peers = 0;         // last factor update: rows of L that arrived from other ranks
+    int64_t row_exchanges = 0, row_fallbacks = 0;   // exchanges carried out / agreed fall-backs to the triangular solve, so far
+    int debug_fail_next_rowx = 0;        // algp_debug_fail_at(3): this rank's next agreement word carries this code
     int pending_pick_error = 0;          // a commit that failed after an exchange: this rank's status word in its next pick
     std::string pending_pick_msg;
     int64_t n_syncs = 0;     // stream synchronisations issued by the library (algp_debug_counter)
@@ -333,6 +342,9 @@ int comm_init_host(algp_ctx* c, int nranks, int rank, algp_allgather_fn fn, void
 int comm_pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_dev, const int64_t* cidx_dev,
                        const int* fresh_dev, int npicks, int status, double* rec5, const char** winner_payload);
 int comm_reserve(algp_ctx* c);
+int comm_agree(algp_ctx* c, const double mine[4], std::vector<double>& all);
+int comm_rows_reserve(algp_ctx* c, size_t bytes_per_rank);
+int comm_rows_gather(algp_ctx* c, size_t bytes_per_rank);
 size_t comm_payload_bytes(const algp_ctx* c);
 int comm_debug_first_max(algp_ctx* c, const double* triples, int nranks, double* out5);
 void dag_release(algp_ctx* c);   // frees the cached task lists of the dependency-driven Cholesky

@@ -35,6 +35,51 @@ def partition(n_items, world_size):
     return [(int(offs[r]), int(offs[r + 1])) for r in range(world_size)]
 
 
+class ShardLink(object):
+    """How an Agent's pool context joins the other ranks of a sharded run (one process and one context per GPU): the
+    rank's place in the job, the transport of the library's collectives, and which rank holds which pool site as a
+    candidate.  `Agent(env, args, comm=ShardLink(...))` then scores only its share of the pool in `greedy`
+    (algp_greedy_sharded: one all-gather per pick) and its factor updates take the rows of the new train sites from
+    their owners (algp_comm_set_owners: one all-gather per planning step) -- agent.py:125-229 with the loop of
+    agent.py:313-354 cut into shards; every rank ends each step with the same picks and the same factor.
+
+    unique_id: the 128 bytes of `_hip.Context.comm_unique_id()` (RCCL over xGMI; one rank creates them, the caller
+    hands them to the others), or all_gather: a callable bytes -> bytes concatenating every rank's bytes in rank order
+    (MPI, gloo, shared memory; also what lets two ranks share one card).
+    layout: 'strided' (site q on rank q mod n: a path's neighbouring sites spread over all owners, so a step's row
+    exchange carries ~1/n of the new rows per rank, and retired static sites thin every shard alike) or 'contiguous'
+    (rank r owns `partition(n_pool, n)[r]`).  Picks are the same either way: equal utilities go to
+    the smaller pool index, which is np.argmax's first maximum (agent.py:349)."""
+
+    def __init__(self, rank, world_size, unique_id=None, all_gather=None, layout='strided'):
+        if (unique_id is None) == (all_gather is None):
+            raise ValueError('give exactly one transport: unique_id (RCCL) or all_gather (host)')
+        if layout not in ('strided', 'contiguous'):
+            raise ValueError("layout must be 'strided' or 'contiguous'")
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.unique_id, self.all_gather, self.layout = unique_id, all_gather, layout
+
+    def owners(self, n_pool):
+        if self.layout == 'strided':
+            return (np.arange(n_pool) % self.world_size).astype(np.int32)
+        own = np.empty(n_pool, dtype=np.int32)
+        for r, (lo, hi) in enumerate(partition(n_pool, self.world_size)):
+            own[lo:hi] = r
+        return own
+
+    def mine(self, n_pool):
+        """Pool sites this rank holds as candidates, ascending."""
+        return np.nonzero(self.owners(n_pool) == self.rank)[0].astype(np.int64)
+
+    def attach(self, ctx, n_pool):
+        """Join `ctx` (its pool already set) to the job: transport, then the owner map."""
+        if self.unique_id is not None:
+            ctx.comm_init(self.world_size, self.rank, self.unique_id)
+        else:
+            ctx.comm_init_host(self.world_size, self.rank, self.all_gather)
+        ctx.comm_set_owners(self.owners(n_pool))
+
+
 class LocalComm(object):
     """world_size == 1: no collective."""
     rank, world_size = 0, 1
@@ -157,7 +202,7 @@ class ShardedGreedy(object):
         best_pos, best_v = -1, -np.inf
         for r in range(len(pairs)):
             v, gp = float(pairs[r, 0]), int(pairs[r, 1])
-            if gp >= 0 and (best_pos < 0 or v > best_v):
+            if gp >= 0 and (best_pos < 0 or v > best_v or (v == best_v and gp < best_pos)):
                 best_v, best_pos = v, gp
         return best_pos, best_v
 

@@ -236,8 +236,25 @@ int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen
  *   code, nobody commits the pick, nobody hangs.  A commit that fails on one rank AFTER the exchange that chose the winner
  *   is reported in that rank's status word of its next pick (every rank returns it from that call); after the LAST pick of
  *   a call it is returned by that rank at once and reported again in the first exchange of its next call -- the one case
- *   in which ranks leave a call with different codes (closing it would take a second collective per call). */
+ *   in which ranks leave a call with different codes (closing it would take a second collective per call).
+ * The active-learning LOOP on sharded candidates (agent.py:125-229: greedy :141 -> _add_samples :66-82 -> predict :196-210,
+ * with the loop of agent.py:313-354 cut into shards) -- algp_comm_set_owners: owner[q] = the rank that holds pool site q as
+ *   a candidate (-1: nobody; NULL clears the map), the same array on every rank, after algp_comm_init[_host] and
+ *   algp_set_pool.  With a map attached algp_factorize_update becomes a COLLECTIVE (every rank calls it with the same
+ *   train set): the sites a step appends to the train set are candidates of one rank each, and that rank's row of V^T is
+ *   the site's new row of the replicated factor left of the tail block -- so instead of solving those rows against the
+ *   kept factor on every rank (38 ms per 256 rows at N = 50 000) the ranks exchange them: a 32-byte agreement word per
+ *   rank (status, first changed row, train size, a hash of the plan), then ONE all-gather of cap rows of the kept width
+ *   per rank, cap = the largest number of new sites any rank owns (every rank derives the same plan from the train set
+ *   and the map).  A rank whose V^T cannot supply its rows (no resident solve for these hyper-parameters / this
+ *   candidate list) says so in the agreement and EVERY rank falls back to the solve; an error (allocation, injected) is
+ *   returned by every rank, the second collective is then not entered by anyone.  With any map other than contiguous
+ *   shards in rank order the pick's first maximum still equals np.argmax in pool order: equal utilities go to the smaller
+ *   pool index.  The calls that follow -- algp_solve_candidates_update on the rank's shard, algp_greedy_sharded -- are
+ *   unchanged.  algp_debug_counter(ctx, 1..4): rows of L the last factor update placed without a triangular solve, how many
+ *   of them came from other ranks, row exchanges so far, agreed fall-backs so far.                                        */
 typedef int (*algp_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
+int algp_comm_set_owners(algp_ctx* ctx, const int32_t* owner, int64_t n_pool);
 int algp_comm_unique_id(void* out128);
 int algp_comm_init(algp_ctx* ctx, int nranks, int rank, const void* unique_id128);
 int algp_comm_init_host(algp_ctx* ctx, int nranks, int rank, algp_allgather_fn fn, void* user);
@@ -265,7 +282,8 @@ int algp_greedy_sharded(algp_ctx* ctx, int criterion, double static_std, double 
  * 0 = while resolving its best candidate (= algp_debug_fail_next_pick), 1 = in the commit of the winner, AFTER the exchange
  * that chose it (the code travels in this rank's status word of its next pick: every rank returns it from that call; after
  * the last pick of a call it is returned by this rank at once and reported again in its next call's first exchange),
- * 2 = the launch that packs its contribution counts as failed (ALGP_ERR_HIP in its status word, the gather still runs). */
+ * 2 = the launch that packs its contribution counts as failed (ALGP_ERR_HIP in its status word, the gather still runs),
+ * 3 = this rank's agreement word of its next sharded algp_factorize_update carries `code`: every rank returns it. */
 int algp_debug_fail_at(algp_ctx* ctx, int where, int code);
 int algp_debug_trsv_stall(algp_ctx* ctx, int block);
 int algp_debug_get_pick(algp_ctx* ctx, int q, void* row_out, int64_t row_capacity, int64_t* ncols_out, double* d_out);
