@@ -22,7 +22,7 @@ KERNEL_RBF, KERNEL_MATERN15 = 0, 1
 CRIT_ENTROPY, CRIT_MUTUAL_INFORMATION = 0, 1
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_OOM, ERR_STATE, ERR_NO_DEVICE = range(7)
 PROF = dict(kmat=0, gemm_chol=1, gemm_trsm=2, potrf_diag=3, trsv=4, rows=5, score=6, gemm_other=7, cholesky=8, trsm=9,
-            gemm_chol_update=10, chol_dag=11, dag_panel=12)
+            gemm_chol_update=10, chol_dag=11, dag_panel=12, tail_cols=13)
 
 _c_ctx = C.c_void_p
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)   # algp_allgather_fn
@@ -98,6 +98,7 @@ SIGNATURES = {
     'algp_debug_fail_at': (C.c_int, [_c_ctx, C.c_int, C.c_int]),
     'algp_debug_get_pick': (C.c_int, [_c_ctx, C.c_int, C.c_void_p, C.c_int64, _i64p, _dblp]),
     'algp_debug_counter': (C.c_int64, [_c_ctx, C.c_int]),
+    'algp_debug_get_factor_rows': (C.c_int, [_c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     'algp_greedy_sharded': (C.c_int, [_c_ctx, C.c_int, C.c_double, C.c_double, C.c_int, _i64p, _dblp]),
 }
 
@@ -419,11 +420,15 @@ class Context(object):
             raise ValueError('unique_id must be the 128 bytes of comm_unique_id()')
         self._check(self.lib.algp_comm_init(self.h, int(nranks), int(rank), C.create_string_buffer(unique_id, 128)))
 
-    def comm_init_host(self, nranks, rank, all_gather):
+    def comm_init_host(self, nranks, rank, all_gather, raw=False):
         """The sharded greedy loop over a transport the caller owns: all_gather(send: bytes) -> bytes must return the
-        concatenation, in rank order, of what every rank passed (algp_comm_init_host)."""
+        concatenation, in rank order, of what every rank passed (algp_comm_init_host).  raw=True: the callable gets
+        (send_address, recv_address, bytes_per_rank) -- the library's pinned staging itself, no copies through Python
+        objects -- and returns 0 for success."""
         def tramp(_user, send, recv, nbytes):
             try:
+                if raw:
+                    return int(all_gather(int(send or 0), int(recv or 0), int(nbytes)))
                 out = all_gather(C.string_at(send, nbytes))
                 if len(out) != nbytes * int(nranks):
                     return 2
@@ -477,6 +482,12 @@ class Context(object):
     def debug_trsv_stall(self, block):
         """The next one-launch forward / backward substitution loses the flag of this 128-block (spin limit 0.2 s)."""
         self._check(self.lib.algp_debug_trsv_stall(self.h, int(block)))
+
+    def debug_factor_rows(self, row0, nrows, ncols):
+        """Rows [row0, row0 + nrows) x columns [0, ncols) of the resident factor (algp_debug_get_factor_rows)."""
+        out = np.empty((int(nrows), int(ncols)), dtype=self.dtype)
+        self._check(self.lib.algp_debug_get_factor_rows(self.h, int(row0), int(nrows), int(ncols), _ptr(out)))
+        return out
 
     def debug_get_pick(self, q):
         """(row, d): pick q since the last solve as every rank committed it -- the winner's row of V^T (ncols values) and

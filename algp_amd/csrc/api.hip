@@ -521,7 +521,7 @@ struct Impl {
         const size_t rowbytes = sizeof(T) * (size_t)Nb;
         // sized by the factor's capacity, not by this step's Nb and cap: the buffers then stay put while the train set grows
         if (st <= 1 && cap > 0) {
-            const int rc = comm_rows_reserve(c, sizeof(T) * (size_t)c->Lld * (size_t)round_up(cap, 8));
+            const int rc = comm_rows_reserve(c, sizeof(T) * (size_t)c->Lld * (size_t)std::max<int64_t>(16, round_up(cap, 8)));
             if (rc != ALGP_OK) st = rc;
         }
         if (st <= 1) {
@@ -829,6 +829,7 @@ struct Impl {
         int nseg = 0;                        // > 0: only the new columns are solved (tail.hip), as 1-2 ranges [seg_c0, seg_c0 + seg_w)
         int64_t seg_c0[2] = {0, 0};
         int seg_w[2] = {0, 0};
+        bool seg_window = false;             // the one range straddles two 128-column blocks of the factor
     };
     static int solve_prepare(algp_ctx* c, int incremental, SolvePlan& pl) {
         const int64_t N = c->N, Npad = c->Npad, M = c->M, Mpad = c->Mpad;
@@ -851,7 +852,17 @@ struct Impl {
                 const int64_t k16 = p0 / 16 * 16, c1 = round_up(N, 16);
                 int n = 0;
                 bool ok = c1 > k16;
-                for (int64_t a = k16; a < c1 && ok;) {
+                // at most 64 new columns: ONE pass over V^T even where they straddle two 128-column blocks of the factor (the
+                // epilogue then takes the inverse of the 128 x 128 window of L at (k16, k16), solve_run); $ALGP_TAIL_STRADDLE=0: a
+                // pass per block as before (16 ms instead of 9.5 for the 40 GB of config 5)
+                const bool straddle_on = !(getenv("ALGP_TAIL_STRADDLE") && atoi(getenv("ALGP_TAIL_STRADDLE")) == 0);
+                if (ok && straddle_on && c1 - k16 <= 64 && k16 / NB != (c1 - 1) / NB && k16 + NB <= Npad) {
+                    pl.seg_c0[0] = k16;
+                    pl.seg_w[0] = (int)(c1 - k16);
+                    pl.seg_window = true;
+                    n = 1;
+                }
+                for (int64_t a = k16; a < c1 && ok && !pl.seg_window;) {
                     const int64_t b = std::min<int64_t>(c1, (a / NB + 1) * NB);
                     if (b - a > 64 || n == 2) { ok = false; break; }
                     pl.seg_c0[n] = a;
@@ -884,7 +895,7 @@ struct Impl {
             }
             if (keep == 0) became_unit.clear();
         }
-        if (keep == 0) pl.nseg = 0;
+        if (keep == 0) { pl.nseg = 0; pl.seg_window = false; }
         pl.keep = keep;
         c->solved = false;
         if (!c->Vt.p || c->ldv_cap < ldv || (keep == 0 && !incremental && c->ldv_cap != ldv) ||
@@ -940,9 +951,15 @@ struct Impl {
         prof_span_begin(c, ALGP_PROF_TRSM, (double)(Npad - keep) * (double)(Npad + keep) * (double)Mpad,
                         sizeof(T) * (double)Mpad * (double)Npad);
         int trc = ALGP_OK;
-        if (pl.nseg > 0) {
+        if (pl.nseg > 0 && pl.seg_window) {
+            trc = ensure(c, c->tailE, sizeof(T) * NB * NB);
+            if (trc == ALGP_OK) trc = trinv_diag_launch<T>(c, p(c->L) + pl.seg_c0[0] * c->Lld + pl.seg_c0[0], c->Lld, p(c->tailE));
+            if (trc == ALGP_OK)
+                trc = tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad, (const T*)nullptr,
+                                          pl.seg_c0[0], pl.seg_w[0], p(c->tailE));
+        } else if (pl.nseg > 0) {
             for (int q = 0; q < pl.nseg && trc == ALGP_OK; ++q)
-                trc = tail_cols_launch<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad,
+                trc = tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad,
                                           p(c->invD) + (pl.seg_c0[q] / NB) * NB * NB, pl.seg_c0[q], pl.seg_w[q]);
         } else if (solve_dag_on && keep == 0 && Mpad / NB > 32 && panel_fits(Npad, Mpad) && c->cur == c->stream)
             trc = solve_dag_panel<T>(c, p(c->L), Npad, c->Lld, p(c->invD), (int*)((double*)c->scal.p + SC_STALL), p(c->Vt), ldc, Mpad, 1);
@@ -1904,7 +1921,7 @@ void algp_destroy(algp_ctx* c) {
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
                       &c->lrow, &c->remote, &c->commbuf, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->rowstat, &c->inv512, &c->inv512_scr, &c->trsm_tmp, &c->splitk, &c->dag_state, &c->dag_stats, &c->trsv_ctrl, &c->miXbar, &c->miXall, &c->miDP, &c->miDQ, &c->miPos, &c->miU, &c->miW, &c->miCol, &c->miH, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
-                      &c->auxVar, &c->auxD, &c->hostStage, &c->rowx};
+                      &c->auxVar, &c->auxD, &c->hostStage, &c->rowx, &c->tailE, &c->tailPart};
     for (DevBuf* b : bufs) release(c, *b);
     dag_release(c);
     comm_destroy(c);
@@ -2207,6 +2224,16 @@ int algp_debug_get_pick(algp_ctx* c, int q, void* row_out, int64_t row_capacity,
         ALGP_HIP(hipStreamSynchronize(c->stream));
     }
     return ALGP_OK;
+}
+int algp_debug_get_factor_rows(algp_ctx* c, int64_t row0, int64_t nrows, int64_t ncols, void* out) {
+    CHECK_CTX(c);
+    if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "debug_get_factor_rows: call algp_factorize first");
+    if (row0 < 0 || nrows < 0 || ncols < 0 || row0 + nrows > c->Npad || ncols > c->Npad || (nrows > 0 && ncols > 0 && !out))
+        return fail(c, ALGP_ERR_BAD_ARG, "debug_get_factor_rows: rows / columns outside the factor");
+    if (nrows == 0 || ncols == 0) return ALGP_OK;
+    ALGP_HIP(hipMemcpy2DAsync(out, c->es * (size_t)ncols, (const char*)c->L.p + (size_t)row0 * c->Lld * c->es, c->es * (size_t)c->Lld,
+                              c->es * (size_t)ncols, (size_t)nrows, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
 }
 int algp_debug_dag_stall(algp_ctx* c, int ticket) {
     CHECK_CTX(c);

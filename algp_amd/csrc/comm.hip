@@ -189,18 +189,22 @@ size_t comm_payload_bytes(const algp_ctx* c) {
 int comm_reserve(algp_ctx* c) {
     const size_t pb = comm_payload_bytes(c);
     const int nr = c->comm_nranks;
-    ALGP_TRY(ensure(c, c->commbuf, pb * (size_t)(nr + 1) + 5 * sizeof(double)));
+    // a train set that grows by a few rows per planning step crosses a 128-row boundary every few steps: reserve 12.5 % more
+    // than this size asks for whenever the buffers have to grow (a re-allocation of the pinned staging costs ~15 ms)
+    const size_t need_dev = pb * (size_t)(nr + 1) + 5 * sizeof(double);
+    if (!c->commbuf.p || c->commbuf.cap < need_dev) ALGP_TRY(ensure(c, c->commbuf, need_dev + need_dev / 8));
     if (c->host_gather) {
         const size_t need = pb * (size_t)(nr + 1);
         if (c->comm_host_cap < need) {
             if (c->comm_host) hipHostFree(c->comm_host);
             c->comm_host = nullptr;
             c->comm_host_cap = 0;
-            if (hipHostMalloc(&c->comm_host, need, hipHostMallocDefault) != hipSuccess) {
+            const size_t want = need + need / 8;
+            if (hipHostMalloc(&c->comm_host, want, hipHostMallocDefault) != hipSuccess) {
                 (void)hipGetLastError();
-                return fail(c, ALGP_ERR_OOM, "comm: hipHostMalloc(" + std::to_string(need) + ") for the host transport's staging failed");
+                return fail(c, ALGP_ERR_OOM, "comm: hipHostMalloc(" + std::to_string(want) + ") for the host transport's staging failed");
             }
-            c->comm_host_cap = need;
+            c->comm_host_cap = want;
         }
     }
     return ALGP_OK;

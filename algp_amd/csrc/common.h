@@ -157,6 +157,8 @@ struct algp_ctx {
     algp::DevBuf acc3;
     algp::DevBuf rowstat;                // per column tile of V^T: row sums of v^2 and v z left by the solve's own launches
     algp::DevBuf splitk;                 // partial products of split-K launches (skinny solves)
+    algp::DevBuf tailPart;               // tail.hip: partial accumulators of the k-split form
+    algp::DevBuf tailE;                  // tail.hip: inverse of the 128 x 128 window of L at the first new column (a range that straddles two blocks)
     algp::DevBuf inv512, inv512_scr, trsm_tmp;   // candidate solve: explicit inverses of the factor's 512-column blocks, their scratch, mpad x 512
     std::vector<algp::DagCache> dag_cache;   // task lists of the dependency-driven Cholesky, per matrix size
     algp::DevBuf dag_state;              // its per-launch tile versions / control words / per-block log-determinants
@@ -376,7 +378,7 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
 // w <= 64, inside one 128-column block whose explicit inverse is invD_blk; lrows = rows of L that exist
 template <typename T>
 int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t ldl, int64_t lrows, const T* invD_blk,
-                     int64_t c0, int w);
+                     int64_t c0, int w, const T* E_window = nullptr);
 // X (npad x npad, holding the identity) <- L^-T (upper triangular; zero parts are never touched)
 template <typename T>
 int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T* L, int64_t ldl, const T* invD);

@@ -15,6 +15,9 @@
 // Orientation: MFMA rows = the new columns (A operand = rows of L), MFMA columns = candidates (B operand = rows of V^T).
 #include "common.h"
 #include "mfma.h"
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
 
 namespace algp {
 
@@ -31,24 +34,32 @@ struct TailArgs {
     const T* E;           // inv(D)[o:, o:] of the tail's 128 x 128 inverse (leading dimension 128), o = c0 mod 128
     int64_t c0;           // first new column = K of the product (a multiple of 16)
     int w;                // new columns (<= 64)
+    // split form (tail_part_kernel + tail_finish_kernel): the k range cut into `nsplit` chunks of `kt_per` k-tiles, unit
+    // u = chunk * nrb + row block; partial accumulators to part[(u * 4 + wave) * nt + tile][2][4][64]
+    int nsplit, kt_per, nrb;
+    T* part;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
+constexpr int TAIL_NST = 3, TAIL_STB = 24576;
+
+// acc += L[c0 .. c0 + 64, k-tiles [kt0, kt1)] (x) X[m0 .. m0 + 128, the same k-tiles]^T for the workgroup's 128 candidate rows;
+// with_ktail: the fp32 half tile behind the last full one as well.  Every wave of the workgroup calls it with the same range.
+// NT: the 16-row tiles of L that carry new columns (ceil(w / 16)), a compile-time constant: the products of a k-tile are one
+// straight run of MFMAs in which consecutive instructions never share an accumulator.
+template <typename T, int NT>
+__device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0, int kt0, int kt1, bool with_ktail,
+                                                typename MF<T>::acc_t (&acc)[4][2], char* smem) {
     // k-tiles of 128 bytes per row (the GEMM's are 64): this kernel lives on HBM bandwidth, and with 64-byte pieces of
     // 128 x 512 different rows in flight it reached 2.7 TB/s (14.6 ms for the 40 GB of config 5) -- every piece opens a
     // DRAM page of its own.  Three stages of 24 KB (8 KB of L rows + 16 KB of V^T rows), two k-tiles in flight.
-    constexpr int NST = 3, STB = 24576;
+    constexpr int NST = TAIL_NST, STB = TAIL_STB;
     using F = MF<T>;
-    using acc_t = typename F::acc_t;
     using chunk_t = typename F::chunk_t;
     constexpr int EPC = F::EPC;
     constexpr int BK = 8 * EPC;                                    // elements per 128-byte row piece
-    __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t m0 = (int64_t)blockIdx.x * 128;
     // DMA: one instruction moves 8 rows x 128 bytes; lane l -> row l >> 3 of the group, LDS slot l & 7.  LDS image
     // [row][8 slots of 16 B], slot = chunk ^ ((row >> 1) & 7): the 16 rows a quarter-wave reads at one chunk index fall
     // into 16 different 16-byte bank groups.  Wave w stages rows 16 w .. 16 w + 15 of L and 32 w .. 32 w + 31 of V^T.
@@ -81,30 +92,25 @@ __global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
     const int aoff0 = fr * 128 + ((fg ^ sw) << 4), aoff1 = fr * 128 + (((4 + fg) ^ sw) << 4);
     const int boff0 = 8192 + (32 * wave + fr) * 128 + ((fg ^ sw) << 4), boff1 = 8192 + (32 * wave + fr) * 128 + (((4 + fg) ^ sw) << 4);
 
-    acc_t acc[4][2];
+    // ALL three stages are in flight: a stage is refilled as soon as every wave holds its fragments in registers (the
+    // second barrier), not one iteration later behind the slowest wave's MFMAs.  With two k-tiles in flight and the
+    // refill issued after the products, the time per k-tile was (memory time) + (MFMA time), not their maximum: 6.9 / 8.4 /
+    // 10.2 / 12.3 ms for 16 / 32 / 48 / 64 new columns over the 40 GB of config 5 (tools/tail_sweep.py).
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
-
-    const int nt = (g.w + 15) >> 4;                                // 16-row tiles of L that carry new columns (wave-uniform)
-    const int nkt = (int)(g.c0 / BK);                              // c0 is a multiple of 16 elements: of BK for fp64; fp32 below
-    const int ktail = (int)(g.c0 - (int64_t)nkt * BK);             // fp32 only: 16 elements left over (half a k-tile)
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
-        if (t < nkt) stage(t, t);
+    for (int t = 0; t < NST; ++t)
+        if (kt0 + t < kt1) stage(t, kt0 + t);
     int st = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (nkt - 1 - kt >= 1) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): this tile landed, the next one may fly (6 DMA per tile)
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int ahead = kt1 - 1 - kt;                             // k-tiles behind this one that have been issued: min(2, ahead)
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F7C);         // vmcnt(12): this tile landed, two may fly (6 DMA per tile)
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F76);    // vmcnt(6)
         else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* base = smem + st * STB;
-        chunk_t a0[4], a1[4], b0[2], b1[2];
+        chunk_t a0[NT], a1[NT], b0[2], b1[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NT; ++i) {
             a0[i] = *reinterpret_cast<const chunk_t*>(base + aoff0 + i * 2048);
             a1[i] = *reinterpret_cast<const chunk_t*>(base + aoff1 + i * 2048);
         }
@@ -113,20 +119,28 @@ __global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
             b0[j] = *reinterpret_cast<const chunk_t*>(base + boff0 + j * 2048);
             b1[j] = *reinterpret_cast<const chunk_t*>(base + boff1 + j * 2048);
         }
-        if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);
+        if (kt + NST < kt1) {                                       // wave-uniform
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragments are in registers ...
+            __builtin_amdgcn_s_barrier();                           // ... and so are everybody's: the stage is free
+            asm volatile("" ::: "memory");
+            stage(st, kt + NST);
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int e = 0; e < EPC; ++e) {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nt) {
-                        acc[i][j] = F::mfma(a0[i][e], b0[j][e], acc[i][j]);
-                        acc[i][j] = F::mfma(a1[i][e], b1[j][e], acc[i][j]);
-                    }
+                for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a0[i][e], b0[j][e], acc[i][j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a1[i][e], b1[j][e], acc[i][j]);
+        }
         st = (st + 1 == NST) ? 0 : st + 1;
     }
-    if (ktail > 0) {
+    const int nkt = (int)(g.c0 / BK);
+    const int ktail = (int)(g.c0 - (int64_t)nkt * BK);             // fp32 only: 16 elements left over (half a k-tile)
+    if (with_ktail && ktail > 0) {
         // fp32, c0 = 16 (mod 32): the last 16 columns as plain fragment loads (64 bytes per row: chunk fg of the row)
         __syncthreads();
         const int64_t k0 = (int64_t)nkt * BK;
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
         for (int j = 0; j < 2; ++j) {
             const chunk_t b = *reinterpret_cast<const chunk_t*>(g.X + (m0 + 32 * wave + 16 * j + fr) * g.ldx + k0 + fg * EPC);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NT; ++i) {
                 int row = 16 * i + fr;
                 if (row >= g.lrows_valid) row = g.lrows_valid - 1;
                 const chunk_t a = *reinterpret_cast<const chunk_t*>(g.Lrows + (int64_t)row * g.ldl + k0 + fg * EPC);
@@ -143,7 +157,16 @@ __global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
             }
         }
     }
+}
 
+// acc holds the full product for the workgroup's 128 candidates: X_new = (B - acc) inv(D)^T into the w new columns
+template <typename T>
+__device__ __forceinline__ void tail_epilogue(const TailArgs<T>& g, int64_t m0, typename MF<T>::acc_t (&acc)[4][2]) {
+    using F = MF<T>;
+    using acc_t = typename F::acc_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15;
     // T = B - acc for the w new columns (element (new column 16 i + row_of, candidate 32 wave + 16 j + fr)); zero beyond w
     const int w = g.w;
     T* Xw = g.X + (m0 + 32 * wave + fr) * g.ldx + g.c0;
@@ -193,15 +216,101 @@ __global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
             }
 }
 
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
+    using acc_t = typename MF<T>::acc_t;
+    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * TAIL_STB];
+    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    acc_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+    tail_accumulate<T, NT>(g, m0, 0, (int)(g.c0 / (8 * MF<T>::EPC)), true, acc, smem);
+    tail_epilogue<T>(g, m0, acc);
+}
+
+// The same product with the k range cut into nsplit chunks: unit u = chunk * nrb + row block, workgroup b takes units b,
+// b + gridDim.x, ... (chunk-major: the workgroups running at one moment mostly walk the same k chunk of the 64 new rows
+// of L, which then stays in the XCDs' L2) and leaves each unit's accumulators in `part`.  Why: one workgroup per 128
+// candidates gives 782 workgroups for config 5's 100 000 candidates on 512 slots (two per CU) -- the second round runs on
+// half a machine (3.6 - 4.4 TB/s) --, and a rank's 12 500 candidates fill 98 of the 512 slots (1.9 TB/s).  nsplit is chosen
+// by the host so that units / slots sits just below an integer.  Fixed assignment, fixed summation order in
+// tail_finish_kernel: the same bits in every run.
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void tail_part_kernel(TailArgs<T> g) {
+    using acc_t = typename MF<T>::acc_t;
+    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * TAIL_STB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int nt = NT;
+    const int nkt = (int)(g.c0 / (8 * MF<T>::EPC));
+    const int units = g.nsplit * g.nrb;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int chunk = u / g.nrb, rb = u - chunk * g.nrb;
+        const int kt0 = chunk * g.kt_per, kt1 = min(nkt, kt0 + g.kt_per);
+        acc_t acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+        __syncthreads();                                           // the previous unit's last LDS reads are done
+        tail_accumulate<T, NT>(g, (int64_t)rb * 128, kt0, kt1, chunk == g.nsplit - 1, acc, smem);
+        T* dst = g.part + ((int64_t)u * 4 + wave) * nt * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+            }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                        // the stores have left before the next unit's DMA is counted
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tail_finish_kernel(TailArgs<T> g) {
+    using acc_t = typename MF<T>::acc_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nt = (g.w + 15) >> 4;
+    const int rb = blockIdx.x;
+    acc_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+    for (int chunk = 0; chunk < g.nsplit; ++chunk) {               // ascending k: one fixed order of summation
+        const T* src = g.part + (((int64_t)chunk * g.nrb + rb) * 4 + wave) * nt * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * 2 + j) * 4 + r) * 64 + lane];
+            }
+    }
+    tail_epilogue<T>(g, (int64_t)rb * 128, acc);
+}
+
 // X[:, c0 : c0 + w) of the mpad rows of X <- the solution's new columns (see the header); c0 a multiple of 16, w <= 64, the
-// columns inside ONE 128-column block of the factor; invD_blk = that block's explicit inverse (128 x 128, ld 128).
+// columns inside ONE 128-column block of the factor, invD_blk = that block's explicit inverse (128 x 128, ld 128) -- or any
+// 16-aligned range of at most 64 columns with E_window = the inverse of the 128 x 128 window of L at (c0, c0).
 template <typename T>
 int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const T* L, int64_t ldl, int64_t lrows, const T* invD_blk,
-                     int64_t c0, int w) {
+                     int64_t c0, int w, const T* E_window) {
     if (mpad <= 0 || w <= 0) return ALGP_OK;
     constexpr int G = 16;
-    if (mpad % 128 || c0 % G || w > 64 || c0 / 128 != (c0 + w - 1) / 128 || ldx % 4 || ldl % 4 || lrows < c0 + w)
-        return fail(c, ALGP_ERR_BAD_ARG, "tail_cols: columns must be a 16-aligned range of at most 64 inside one 128-column block");
+    if (mpad % 128 || c0 % G || w > 64 || (!E_window && c0 / 128 != (c0 + w - 1) / 128) || ldx % 4 || ldl % 4 || lrows < c0 + w)
+        return fail(c, ALGP_ERR_BAD_ARG, "tail_cols: columns must be a 16-aligned range of at most 64 (inside one 128-column block "
+                                         "unless the inverse of the range's own window is supplied)");
     TailArgs<T> g;
     g.X = X;
     g.ldx = ldx;
@@ -209,15 +318,60 @@ int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
     g.ldl = ldl;
     g.lrows_valid = (int)std::min<int64_t>(64, lrows - c0);
     const int64_t o = c0 % 128;
-    g.E = invD_blk + o * 128 + o;
+    // E_window: the explicit inverse (ld 128) of the 128 x 128 window of L whose corner is (c0, c0) -- for a range that
+    // straddles two 128-column blocks of the factor, where no stored block inverse covers it
+    g.E = E_window ? E_window : invD_blk + o * 128 + o;
     g.c0 = c0;
     g.w = w;
+    g.nsplit = 1;
+    g.kt_per = 0;
+    g.nrb = 0;
+    g.part = nullptr;
+    // One workgroup per 128 rows leaves the last round of workgroups on a part of the machine (or, for a rank's share of
+    // the candidates, never fills it): cut the k range so that the units fill the 512 slots evenly ($ALGP_TAIL_SPLIT=0: never).
+    const int nrb = (int)(mpad / 128), slots = 512;
+    const int nkt = (int)(c0 / (16 / sizeof(T) * 8));
+    int best = 1;
+    {
+        static const bool split_on = !(getenv("ALGP_TAIL_SPLIT") && atoi(getenv("ALGP_TAIL_SPLIT")) == 0);
+        auto eff = [&](int s_) { const double r = (double)s_ * nrb / slots; return r / ceil(r); };
+        double be = eff(1);
+        // worth two launches and the partials' round trip only where the plain launch wastes more than 6 % of the machine
+        for (int s_ = 2; split_on && be < 0.94 && s_ <= 16 && nkt / s_ >= 48; ++s_)
+            if (eff(s_) > be + 0.02) { be = eff(s_); best = s_; }
+    }
     ProfScope ps(c, klass, 2.0 * (double)mpad * (double)c0 * w, sizeof(T) * ((double)mpad * (double)c0 + 64.0 * (double)c0));
-    hipLaunchKernelGGL(tail_cols_kernel<T>, dim3((unsigned)(mpad / 128)), dim3(256), 0, c->cur, g);
+    const int nt = (w + 15) / 16;
+    if (best == 1) {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((tail_cols_kernel<T, 1>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+            case 2: hipLaunchKernelGGL((tail_cols_kernel<T, 2>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+            case 3: hipLaunchKernelGGL((tail_cols_kernel<T, 3>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+            default: hipLaunchKernelGGL((tail_cols_kernel<T, 4>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+        }
+        ALGP_HIP(hipGetLastError());
+        return ALGP_OK;
+    }
+    ALGP_TRY(ensure(c, c->tailPart, sizeof(T) * (size_t)best * (size_t)nrb * 4 * (size_t)nt * 512));
+    g.nsplit = best;
+    g.kt_per = (nkt + best - 1) / best;
+    g.nrb = nrb;
+    g.part = (T*)c->tailPart.p;
+    const dim3 pgrid((unsigned)std::min(slots, best * nrb));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((tail_part_kernel<T, 1>), pgrid, dim3(256), 0, c->cur, g); break;
+        case 2: hipLaunchKernelGGL((tail_part_kernel<T, 2>), pgrid, dim3(256), 0, c->cur, g); break;
+        case 3: hipLaunchKernelGGL((tail_part_kernel<T, 3>), pgrid, dim3(256), 0, c->cur, g); break;
+        default: hipLaunchKernelGGL((tail_part_kernel<T, 4>), pgrid, dim3(256), 0, c->cur, g); break;
+    }
+    ALGP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(tail_finish_kernel<T>, dim3((unsigned)nrb), dim3(256), 0, c->cur, g);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
-template int tail_cols_launch<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, int64_t, const double*, int64_t, int);
-template int tail_cols_launch<float>(algp_ctx*, int, float*, int64_t, int64_t, const float*, int64_t, int64_t, const float*, int64_t, int);
+template int tail_cols_launch<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, int64_t, const double*, int64_t, int,
+                                      const double*);
+template int tail_cols_launch<float>(algp_ctx*, int, float*, int64_t, int64_t, const float*, int64_t, int64_t, const float*, int64_t, int,
+                                     const float*);
 
 }  // namespace algp

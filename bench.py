@@ -221,15 +221,26 @@ def extra_c3(_hip, device):
     return out
 
 
-def extra_c5(_hip, device, picks):
-    """BASELINE config 5 on one GPU: 50 000-point field fp64, 100 000 candidates: one from-scratch planning step, then 10
-    steps of the active-learning loop (each appends the 4 picks + 28 mobile sites) through the incremental factor."""
-    rng = np.random.RandomState(5)
-    R, C = 250, 200
+def _c5_field(rng, R=250, C=200, M=100000):
     grid, field = mog_field(R, C, rng)
-    N0, M = len(grid), 100000
     cand = candidate_lattice(M, R, C, 2) + 0.03 * rng.standard_normal((M, 2))
-    pool = np.vstack([grid, cand])
+    return grid, field, np.vstack([grid, cand])
+
+
+def _pct(v, q):
+    return float(np.percentile(np.asarray(v, dtype=np.float64), q))
+
+
+def extra_c5(_hip, device, picks, steps=200, emu_steps=40):
+    """BASELINE config 5: 50 000-point field fp64, 100 000 candidates, the active-learning loop (reference agent.py:125-229:
+    greedy :141 -> _add_samples :66-82 -> refit :196-210) -- on ONE GPU: one from-scratch planning step, then `steps`
+    incremental ones (each appends the picks + 26 mobile readings: factor update, the new columns of V^T, 4 picks), the
+    second half with the library's event pairs on for the roofline of the kernel that dominates the step
+    (tail_cols_kernel: s * M * N_old bytes streamed once).  Then `c5_rank_of_8`: the step of one rank of an 8-rank run of
+    the same loop (see c5_rank_of_8)."""
+    rng = np.random.RandomState(5)
+    grid, field, pool = _c5_field(rng)
+    N0, M = len(grid), len(pool) - len(grid)
     c = _hip.Context(np.float64, device=device)
     c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
     c.set_pool(pool)
@@ -239,11 +250,17 @@ def extra_c5(_hip, device, picks):
     static = np.zeros(len(pool), bool)
     static[:N0] = var == 0.01
     cidx = np.arange(N0, N0 + M)
-    times, rows, chol_ms = [], [], None
-    for s in range(11):
-        if s == 0:
+    times, rows, chol_ms, crossing = [], [], None, []
+    prof_from = steps // 2 + 1
+    tail = None
+    t_loop = None
+    for s in range(steps + 1):
+        if s == 0 or s == prof_from:
             c.prof_enable(True)
             c.prof_reset()
+        if s == 1:
+            c.sync()
+            t_loop = time.perf_counter()
         t0 = time.perf_counter()
         rows.append(int(len(idx)))
         # incremental=True from the first step, as algp_amd/agent.py calls it: with nothing resident it is a from-scratch
@@ -252,35 +269,249 @@ def extra_c5(_hip, device, picks):
         c.set_train(idx, y, var)
         c.factorize(incremental=True)
         c.set_candidates(cidx, prior_includes_noise=True)
-        c.solve_candidates(incremental=True, alive=~static[cidx])
+        kc = c.solve_candidates(incremental=True, alive=~static[cidx])
         pk = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, picks)
         c.sync()
         times.append((time.perf_counter() - t0) * 1e3)
+        crossing.append(bool(s > 0 and kc % 128 == 0 and kc < len(idx) - 64))     # the 128-column blocks were re-solved, not the tail
         if s == 0:
             chol_ms = c.prof_get('cholesky')['ms']
             trsm = c.prof_get('trsm')
-            gt = c.prof_get('gemm_trsm')
             c.prof_enable(False)
         static[pk] = True
-        mob = cidx[rng.permutation(M)[:28]]
+        mob = cidx[rng.permutation(M)[:26]]
         mob = mob[~np.isin(mob, idx) & ~np.isin(mob, pk)]
         idx = np.r_[idx, pk, mob]
         var = np.r_[var, np.full(len(pk), 0.01), np.full(len(mob), 1.0)]
         y = np.r_[y, rng.uniform(0, 1, len(pk) + len(mob))]
+    c.sync()
+    loop_s = time.perf_counter() - t_loop
+    tail = c.prof_get('tail_cols')
+    gt = c.prof_get('gemm_trsm')
+    c.prof_enable(False)
     dev_gb = c.device_bytes() / 1e9
     c.close()
     ctf = N0 ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12
     ttf = float(N0) ** 2 * M / (trsm['ms'] * 1e-3) / 1e12
-    return {'workload': 'C5 on one GPU: 50 000-point field, fp64, 100 000 candidates, %d picks/step' % picks, 'dtype': 'f64',
-            'from_scratch_step_ms': times[0], 'incremental_step_ms_median': float(np.median(times[1:])),
-            'incremental_step_ms_max': float(np.max(times[1:])), 'incremental_steps': len(times) - 1,
-            'step_ms': [round(t, 2) for t in times], 'train_rows_per_step': rows,
-            'fit_ms': chol_ms, 'cholesky_tflops': ctf, 'device_gb': dev_gb,
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<double> (candidate TRSM, N^2 M / wall time of the solve)',
-                         'achieved': ttf, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ttf / FP64_MATRIX_PEAK_TFLOPS},
-            'cholesky_roofline': {'achieved': ctf, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'frac': ctf / FP64_MATRIX_PEAK_TFLOPS,
-                                  'note': 'N^3/3 over the whole fit (kernel build + factorisation + z); launch sequence of '
-                                          'potrf.hip (the one-launch task list is used up to N = 24 576)'}}
+    inc = np.array(times[1:])
+    unprof, prof = inc[:prof_from - 1], inc[prof_from - 1:]
+    cross = np.array(crossing[1:])
+    tail_gbs = tail['bytes'] / (tail['ms'] * 1e-3) / 1e9 if tail['ms'] > 0 else None
+    out = {'workload': 'C5 on one GPU: 50 000-point field, fp64, 100 000 candidates, %d picks + 26 mobile readings per step, %d '
+                       'incremental steps after one from-scratch step' % (picks, steps), 'dtype': 'f64',
+           'from_scratch_step_ms': times[0], 'incremental_steps': int(steps), 'loop_total_s': loop_s,
+           'incremental_step_ms_median': float(np.median(unprof)), 'incremental_step_ms_p95': _pct(unprof, 95),
+           'incremental_step_ms_max': float(np.max(unprof)),
+           'incremental_step_ms_median_with_event_pairs': float(np.median(prof)),
+           'block_crossing_steps': int(cross.sum()),
+           'block_crossing_step_ms_median': float(np.median(inc[cross])) if cross.any() else None,
+           'plain_step_ms_median': float(np.median(inc[~cross])),
+           'step_ms_first_20': [round(t, 2) for t in times[:21]],
+           'train_rows_first_last': [rows[0], rows[-1]],
+           'fit_ms': chol_ms, 'cholesky_tflops': ctf, 'device_gb': dev_gb,
+           'incremental_roofline': {'bound': 'hbm', 'kernel': 'tail_cols_kernel<double> (the new columns of V^T after an append)',
+                                    'achieved': tail_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                    'frac': tail_gbs / HBM_PEAK_GBS if tail_gbs else None,
+                                    'launches': tail['launches'], 'avg_launch_ms': tail['ms'] / max(1, tail['launches']),
+                                    'algorithmic_bytes_per_launch': tail['bytes'] / max(1, tail['launches']),
+                                    'gemm_launches_in_block_crossing_steps': gt['launches'],
+                                    'note': 'achieved = s * (Mpad * N_old + 64 * N_old) bytes (V^T read once + the new rows of L) / the '
+                                            'kernel\'s own duration (HIP events on its stream), steps %d..%d' % (prof_from, steps)},
+           'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel_dma4<double> (candidate TRSM, N^2 M / wall time of the solve)',
+                        'achieved': ttf, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ttf / FP64_MATRIX_PEAK_TFLOPS},
+           'cholesky_roofline': {'achieved': ctf, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'frac': ctf / FP64_MATRIX_PEAK_TFLOPS,
+                                 'note': 'N^3/3 over the whole fit (kernel build + factorisation + z); launch sequence of '
+                                         'potrf.hip (the one-launch task list is used up to N = 24 576)'}}
+    try:
+        out['c5_rank_of_8'] = c5_rank_of_8(_hip, device, picks, emu_steps)
+        out['c5_rank_of_8']['speedup_vs_1_gpu_step'] = out['incremental_step_ms_median'] / out['c5_rank_of_8']['ms_per_step']
+    except Exception as e:
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        out['c5_rank_of_8'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
+
+
+def c5_rank_of_8(_hip, device, picks, steps=40, nranks=8, ranks=(0, 7), layout='strided', field=None):
+    """What ONE rank of an 8-rank run of config 5's loop does per planning step, measured on this GPU through the product
+    path: the replicated factor update with the new train sites' rows arriving in the row exchange
+    (algp_comm_set_owners), the new columns of the rank's 12 500 rows of V^T, 4 picks through algp_greedy_sharded --
+    over algp_comm_init_host(8, r, fn) with a raw callback that fabricates the 7 absent ranks from a one-rank
+    "teacher" context running the same loop in lockstep: the agreement words (copies of this rank's), the rows of L of
+    the sites other ranks own (the teacher's own new factor rows: the same numbers to rounding), the winners' rows and
+    statistics per pick.  Picks are asserted equal to the teacher's at every step.  In the time: everything the rank's
+    process does in a step, the host transport's staging copies (D2H of its own rows, H2D of all ranks') and
+    synchronisations included.  Not in it: xGMI wire time and skew.  The absent ranks' rows are written into the
+    library's pinned staging BEFORE the step (as a transport's receive would have left them there); the callback
+    copies only headers and this rank's own slice."""
+    import ctypes
+    import struct
+    from algp_amd.sharded import ShardLink
+    rng = np.random.RandomState(5)
+    if field is None:
+        grid, fld, pool = _c5_field(rng)
+    else:
+        grid, fld, pool = field
+    N0, M = len(grid), len(pool) - len(grid)
+    n = len(pool)
+    SS, SM = 0.1, 1.0
+    es = 8
+
+    def make():
+        c = _hip.Context(np.float64, device=device)
+        c.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+        c.set_pool(pool)
+        return c
+    teacher = make()
+    owners = ShardLink(0, nranks, all_gather=lambda b: b, layout=layout).owners(n)
+    cidx = np.arange(N0, n)
+    emus = []
+    for r in ranks:
+        e = make()
+        st = {'r': r, 'q': 0, 'picks': None, 'rows_ptr': None, 'rows_plan': None, 'refills': 0, 'calls': [0, 0, 0]}
+
+        def fn(send, recv, nbytes, st=st):
+            r = st['r']
+            if nbytes == 32:                                         # the factor update's agreement word: everyone agrees
+                st['calls'][0] += 1
+                for k in range(nranks):
+                    ctypes.memmove(recv + 32 * k, send, 32)
+                return 0
+            if nbytes == st.get('pb'):                                # one pick's exchange
+                st['calls'][1] += 1
+                q = min(st['q'], len(st['picks']) - 1)
+                pk, owner, util, d, row = st['picks'][q]
+                absent = struct.pack('<4d', float('-inf'), -1.0, 0.0, 0.0)
+                for k in range(nranks):
+                    if k != r:
+                        ctypes.memmove(recv + nbytes * k, absent, 32)
+                if owner != r:
+                    o = recv + nbytes * owner
+                    ctypes.memmove(o, struct.pack('<4d', util, float(pk), 0.0, d), 32)
+                    ctypes.memmove(o + 32, row.ctypes.data, row.nbytes)
+                ctypes.memmove(recv + nbytes * r, send, nbytes)
+                if struct.unpack('<d', ctypes.string_at(send + 16, 8))[0] == 0.0:
+                    st['q'] += 1
+                return 0
+            # the row exchange: cap rows of Nb elements per rank
+            st['calls'][2] += 1
+            plan = st['rows_plan']
+            if plan is None or plan['bytes'] != nbytes:
+                return 7
+            if st['rows_ptr'] != send:                               # staging moved (first use, or it grew): fill it now
+                st['rows_ptr'] = send                                # [own rows | every rank's rows]: the base is what stays put
+                st['refills'] += 1
+                ctypes.memmove(recv, plan['buf'].ctypes.data, plan['buf'].nbytes)
+            ctypes.memmove(recv + nbytes * r, send, nbytes)
+            return 0
+        e.comm_init_host(nranks, r, fn, raw=True)
+        e.comm_set_owners(owners)
+        emus.append((e, st, np.nonzero(owners[N0:] == r)[0] + N0))
+    idx = np.arange(N0)
+    var = np.where(rng.uniform(size=N0) < 0.5, SS ** 2, SM ** 2)
+    y = np.maximum(fld + rng.standard_normal(N0) * np.sqrt(var), 0.0)
+    static = np.zeros(n, bool)
+    static[:N0] = var == SS ** 2
+    per_rank = {str(r): [] for r in ranks}
+    phases = bool(os.environ.get('C5_PHASES'))          # synchronise after each call and report the split (slower steps)
+    phase_log = {}
+    caps, nnew_log = [], []
+    nnew = 0
+    try:
+        for s in range(steps + 1):
+            Npad = (len(idx) + 127) // 128 * 128
+            p0 = len(idx) - nnew
+            Nb = p0 // 128 * 128
+            # the teacher's step (untimed): picks, their utilities, statistics and rows; its new factor rows
+            teacher.set_train(idx, y, var)
+            teacher.factorize(incremental=True)
+            teacher.set_candidates(cidx, prior_includes_noise=True)
+            teacher.solve_candidates(incremental=True, alive=~static[cidx])
+            new_rows = teacher.debug_factor_rows(p0, nnew, Nb) if (s > 0 and nnew > 0) else None
+            pk, ut = teacher.greedy(_hip.CRIT_ENTROPY, SS, SM, picks, want_utilities=True)
+            pk = [int(p) for p in pk]
+            util = [float(np.nanmax(ut[q])) for q in range(picks)]
+            del ut
+            prow = [teacher.debug_get_pick(q) for q in range(picks)]
+            pb = 32 + ((Npad + 128) * es + 15) // 16 * 16
+            for e, st, mine in emus:
+                r = st['r']
+                st['pb'], st['q'] = pb, 0
+                st['picks'] = [(pk[q], int(owners[pk[q]]), util[q], prow[q][1], prow[q][0]) for q in range(picks)]
+                if new_rows is not None:
+                    own = owners[idx[p0:]]
+                    cnt = np.bincount(own, minlength=nranks)
+                    cap = int(cnt.max())
+                    buf = np.zeros((nranks, cap, Nb), dtype=np.float64)
+                    slot = np.zeros(nranks, dtype=np.int64)
+                    for i, o in enumerate(own):
+                        if o != r:
+                            buf[o, slot[o]] = new_rows[i]
+                        slot[o] += 1
+                    st['rows_plan'] = {'bytes': cap * Nb * es, 'buf': buf}
+                    if st['rows_ptr'] is not None:                   # as a transport's receive would have left them
+                        ctypes.memmove(st['rows_ptr'] + cap * Nb * es, buf.ctypes.data, buf.nbytes)
+                    if r == ranks[0]:
+                        caps.append(cap)
+                e.sync()
+                ph = []
+                t0 = tp = time.perf_counter()
+
+                def mark(tp):
+                    if phases:
+                        e.sync()
+                        ph.append((time.perf_counter() - tp) * 1e3)
+                    return time.perf_counter()
+                e.set_train(idx, y, var)
+                tp = mark(tp)
+                e.factorize(incremental=True)
+                tp = mark(tp)
+                e.set_candidates(mine, prior_includes_noise=True)
+                tp = mark(tp)
+                e.solve_candidates(incremental=True, alive=~static[mine])
+                tp = mark(tp)
+                got = [int(p) for p in e.greedy_sharded(_hip.CRIT_ENTROPY, SS, SM, picks)]
+                e.sync()
+                mark(tp)
+                per_rank[str(r)].append((time.perf_counter() - t0) * 1e3)
+                if phases and s > 2:
+                    phase_log.setdefault(str(r), []).append(ph)
+                if got != pk:
+                    raise RuntimeError('step %d: rank %d of %d picked %s, the one-rank loop %s' % (s, r, nranks, got, pk))
+                if s > 0 and (e.counter(4) != 0 or e.counter(1) != Npad - p0):
+                    raise RuntimeError('step %d: rank %d fell back to the triangular solve (%d fall-backs, %d rows placed)'
+                                       % (s, r, e.counter(4), e.counter(1)))
+            static[pk] = True
+            mob = cidx[rng.permutation(M)[:26]]
+            mob = mob[~np.isin(mob, idx) & ~np.isin(mob, pk)]
+            nnew = len(pk) + len(mob)
+            nnew_log.append(nnew)
+            idx = np.r_[idx, pk, mob]
+            var = np.r_[var, np.full(len(pk), SS ** 2), np.full(len(mob), SM ** 2)]
+            y = np.r_[y, rng.uniform(0, 1, nnew)]
+        out = {'workload': 'one rank of %d of config 5\'s loop: N0 = %d train rows (replicated factor), %d of %d candidates (%s owner map), '
+                           '%d picks + 26 mobile readings per step, %d incremental steps' % (nranks, N0, len(emus[0][2]), M, layout, picks, steps),
+               'ranks': {}, 'rows_per_rank_in_the_exchange_median': float(np.median(caps)) if caps else None,
+               'new_train_rows_per_step_median': float(np.median(nnew_log))}
+        for (e, st, mine) in emus:
+            t = np.array(per_rank[str(st['r'])][1:])
+            # the first incremental steps allocate the exchange's buffers (pinned staging: tens of ms once)
+            tt = t[2:] if len(t) > 4 else t
+            out['ranks'][str(st['r'])] = {'candidates': int(len(mine)), 'from_scratch_step_ms': per_rank[str(st['r'])][0],
+                                          'ms_per_step_median': float(np.median(tt)), 'ms_per_step_p95': _pct(tt, 95),
+                                          'ms_per_step_max': float(np.max(tt)), 'step_ms_first_12': [round(v, 2) for v in t[:12]],
+                                          'row_exchanges': e.counter(3), 'fallbacks': e.counter(4),
+                                          'staging_fills_inside_the_timed_step': st['refills'],
+                                          'callbacks_agree_pick_rows': st['calls']}
+        if phases:
+            out['phase_ms_median_set_train_factorize_set_candidates_solve_picks'] = {
+                r: [round(float(v), 3) for v in np.median(np.array(p), axis=0)] for r, p in phase_log.items()}
+        out['ms_per_step'] = max(v['ms_per_step_median'] for v in out['ranks'].values())
+        return out
+    finally:
+        teacher.close()
+        for e, _, _ in emus:
+            e.close()
 
 
 def extra_mi(_hip, device):

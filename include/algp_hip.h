@@ -62,7 +62,8 @@ enum {
                                       * counted here instead: the "dense panel update" of the blocked factorisation */
     ALGP_PROF_CHOL_DAG = 11,   /* the Cholesky as one dependency-driven launch (chol_dag.hip): the whole factorisation */
     ALGP_PROF_DAG_PANEL = 12,  /* the same launch carrying a row panel: factorisation + candidate solve (or + L^-T), or the solve alone */
-    ALGP_PROF_COUNT = 13
+    ALGP_PROF_TAIL_COLS = 13,  /* tail_cols_kernel: the new columns of V^T after an append (HBM-bound: s * M * N_old bytes) */
+    ALGP_PROF_COUNT = 14
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
@@ -287,6 +288,10 @@ int algp_greedy_sharded(algp_ctx* ctx, int criterion, double static_std, double 
 int algp_debug_fail_at(algp_ctx* ctx, int where, int code);
 int algp_debug_trsv_stall(algp_ctx* ctx, int block);
 int algp_debug_get_pick(algp_ctx* ctx, int q, void* row_out, int64_t row_capacity, int64_t* ncols_out, double* d_out);
+/* algp_debug_get_factor_rows: rows [row0, row0 + nrows) of the resident factor, columns [0, ncols), row-major into out (the
+ * context's dtype) -- what the owners of a step's new train sites contribute to the row exchange; bench.py uses it to
+ * fabricate the seven absent ranks of an eight-rank config-5 step on one GPU. */
+int algp_debug_get_factor_rows(algp_ctx* ctx, int64_t row0, int64_t nrows, int64_t ncols, void* out);
 int algp_debug_first_max(algp_ctx* ctx, const double* triples, int nranks, double out5[5]);
 int algp_debug_set_trsm_chunks(algp_ctx* ctx, int chunks);
 int algp_debug_fail_next_pick(algp_ctx* ctx, int code);

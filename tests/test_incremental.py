@@ -187,8 +187,11 @@ def test_only_the_new_columns_are_solved_after_an_append(dtname, monkeypatch):
     append added (tail.hip: one or two ranges of <= 64 columns, 16-aligned, each inside a 128-column block of the factor)
     instead of the whole open 128-block.  Appends chosen to hit: one range whose first column is 16 (mod 32) -- the fp32
     kernel's half k-tile --, two ranges across a block boundary with the first 64 wide, an append too wide for it (the
-    128-blocks again), a range ending on a block boundary.  Every step against a from-scratch context and against the
-    128-block order ($ALGP_TAIL_COLS=0) on a copy of the state."""
+    128-blocks again), a range ending on a block boundary, and a range of <= 64 columns that STRADDLES a block boundary
+    (one pass over V^T with the inverse of the window of L at its first column; two passes before round 5).  Every step
+    against a from-scratch context, against the 128-block order ($ALGP_TAIL_COLS=0) on a copy of the state, and -- a tail
+    step's own anchor -- against the NumPy oracle's from-scratch posterior (O.posterior_chol, utils.py:293-319) on 200
+    sampled candidates."""
     dt = np.float64 if dtname == 'f64' else np.float32
     tol, loose = (1e-9, 1e-10) if dt == np.float64 else (3e-3, 3e-4)
     rng = np.random.RandomState(4)
@@ -211,7 +214,7 @@ def test_only_the_new_columns_are_solved_after_an_append(dtname, monkeypatch):
         c_.factorize(incremental=True)
         c_.set_candidates(cand, prior_includes_noise=False)
         assert c_.solve_candidates(incremental=True) == 0
-    expect = [(20, 1, 2096), (60, 2, 2112), (70, 0, 2176), (50, 1, 2240), (14, 2, 2288)]      # rows added, tail launches, kept columns
+    expect = [(20, 1, 2096), (60, 2, 2112), (70, 0, 2176), (50, 1, 2240), (14, 1, 2288)]      # rows added, tail launches, kept columns
     for add, launches, kept_want in expect:
         idx = np.arange(len(idx) + add)
         for which, c_ in (('tail', c), ('blocks', b)):
@@ -223,14 +226,14 @@ def test_only_the_new_columns_are_solved_after_an_append(dtname, monkeypatch):
             c_.prof_enable(True)
             c_.prof_reset()
             kept = c_.solve_candidates(incremental=True)
-            got = c_.prof_get('gemm_trsm')['launches']
+            got, gemms = c_.prof_get('tail_cols')['launches'], c_.prof_get('gemm_trsm')['launches']
             c_.prof_enable(False)
             if which == 'blocks':
                 monkeypatch.delenv('ALGP_TAIL_COLS')
                 assert kept == (len(idx) - add) // 128 * 128
             else:
                 assert kept == kept_want, (add, kept)
-                assert got == launches or (launches == 0 and got >= 2), (add, got)       # 0: too wide, the 128-blocks
+                assert got == launches and (gemms == 0) == (launches > 0), (add, got, gemms)     # 0: too wide, the 128-blocks
         f = ctx()
         f.set_train(idx, y[idx], v[idx])
         f.factorize()
@@ -242,6 +245,10 @@ def test_only_the_new_columns_are_solved_after_an_append(dtname, monkeypatch):
         scale = max(1.0, np.max(np.abs(mu_f)))
         assert np.max(np.abs(mu - mu_f)) < tol * scale and np.max(np.abs(pv - pv_f)) < tol, (add, 'tail vs scratch')
         assert np.max(np.abs(mu - mu_b)) < loose * scale and np.max(np.abs(pv - pv_b)) < loose, (add, 'tail vs blocks')
+        samp = rng.permutation(M)[:200]
+        o = O.posterior_chol(HYP, X[idx], y[idx], X[cand[samp]], v[idx])
+        otol = 1e-8 if dt == np.float64 else 3e-3
+        assert np.max(np.abs(mu[samp] - o['mu'])) < otol * scale and np.max(np.abs(pv[samp] - o['var'])) < otol, (add, 'tail vs oracle')
     c.close()
     b.close()
 
