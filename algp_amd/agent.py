@@ -42,7 +42,7 @@ class Agent(object):
         candidates of `greedy` over several GPUs; every rank constructs the same agent on the same environment and
         calls the same methods (the library's collectives sit inside greedy and the factor updates)."""
         self.env = env
-        self.comm = comm if (comm is not None and comm.world_size > 1) else None
+        self._comm = comm if (comm is not None and comm.world_size > 1) else None
         self.learn_likelihood_noise = learn_likelihood_noise
         self._init_model(args)
         self.static_std = args.static_std if static_std is None else static_std
@@ -70,6 +70,11 @@ class Agent(object):
             self.static_data = deepcopy(parent_agent.static_data)
             self.mobile_data = deepcopy(parent_agent.mobile_data)
             self.collected = deepcopy(parent_agent.collected)
+
+    @property
+    def comm(self):
+        """The job's ShardLink, or None for a one-GPU agent (also for objects built without __init__, as some tests do)."""
+        return getattr(self, '_comm', None)
 
     # ---- model plumbing (agent.py:34-45) --------------------------------------------------------
     def _init_model(self, args):
@@ -445,15 +450,15 @@ class Agent(object):
     def _path_utilities_rows(self, c, paths, static, mobile0, batched=True):
         """Entropy utility of every path relative to the common base (row form).  Batched: ONE factor update + ONE
         candidate-solve update for the base, then the posterior block of every path on the device at once
-        (algp_score_paths); the per-path loop (one factor update per path) remains for paths of more than 64 new
-        sites and as the cross-check of the tests."""
+        (algp_score_paths: paths of up to 256 new sites, config 5's field rows); the per-path loop (one factor update per
+        path) remains for longer paths, for sharded agents and as the cross-check of the tests."""
         n = self.env.num_samples
         pen = CONST + 0.5 * np.log(self.static_std ** 2 + self.mobile_std ** 2)     # per site that gets a second row
         clean = [[int(j) for j in dict.fromkeys(int(v) for v in path) if j != -1 and not mobile0[j]] for path in paths]
         if self.comm is not None:
             batched = False          # a shard does not hold every path site's row of V^T: the per-path factor updates run
                                      # on every rank alike (replicated factor; their new rows come through the row exchange)
-        if batched and max((len(p) for p in clean), default=0) <= 64:
+        if batched and max((len(p) for p in clean), default=0) <= 256:
             A, is_static = self._train_rows(static, mobile0)
             c.set_train(A, np.zeros(len(A)), self._rows_noise(is_static))
             c.factorize(incremental=True)

@@ -337,6 +337,9 @@ template <typename T>
 int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet_acc, int* info,
                       int64_t block_row0);
 
+template <typename T>
+int potrf_diag_batched_launch(algp_ctx* c, T* A, int64_t sA, int64_t lda, T* inv_out, int64_t sInv, double* logdet, int* info, int batch);
+
 int comm_unique_id(void* out128, std::string* why);
 int comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128);
 void comm_destroy(algp_ctx* c);

@@ -39,6 +39,26 @@ int potrf_diag_launch(algp_ctx* c, T* A, int64_t lda, T* inv_out, double* logdet
 template int potrf_diag_launch<double>(algp_ctx*, double*, int64_t, double*, double*, int*, int64_t);
 template int potrf_diag_launch<float>(algp_ctx*, float*, int64_t, float*, double*, int*, int64_t);
 
+// `batch` independent 128 x 128 blocks (block b at A + b * sA): factor + inverse + log det (to logdet[b], added) + first bad
+// pivot (info[b], 1-based) -- the per-path blocks of algp_score_paths
+template <typename T>
+__global__ __launch_bounds__(256) void potrf_diag_batched_kernel(T* A, int64_t sA, int64_t lda, T* inv_out, int64_t sInv, double* logdet,
+                                                                  int* info) {
+    __shared__ DiagShared<T> sh;
+    const int64_t b = blockIdx.x;
+    diag128_run<T, true>(sh, A + b * sA, lda, inv_out + b * sInv, logdet + b, true, info + b, 0);
+}
+template <typename T>
+int potrf_diag_batched_launch(algp_ctx* c, T* A, int64_t sA, int64_t lda, T* inv_out, int64_t sInv, double* logdet, int* info, int batch) {
+    if (batch <= 0) return ALGP_OK;
+    ProfScope ps(c, ALGP_PROF_POTRF_DIAG, 128.0 * 128.0 * 128.0 * batch, sizeof(T) * 3.0 * 128.0 * 128.0 * batch);
+    hipLaunchKernelGGL(potrf_diag_batched_kernel<T>, dim3((unsigned)batch), dim3(256), 0, c->cur, A, sA, lda, inv_out, sInv, logdet, info);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int potrf_diag_batched_launch<double>(algp_ctx*, double*, int64_t, int64_t, double*, int64_t, double*, int*, int);
+template int potrf_diag_batched_launch<float>(algp_ctx*, float*, int64_t, int64_t, float*, int64_t, double*, int*, int);
+
 template <typename T>
 int trinv_diag_launch(algp_ctx* c, const T* A, int64_t lda, T* inv_out) {
     hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(1), dim3(256), 0, c->cur, const_cast<T*>(A), lda, inv_out,

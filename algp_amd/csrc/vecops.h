@@ -37,6 +37,12 @@ template <typename T>
 int path_score_launch(algp_ctx* c, const int64_t* cpos, const int64_t* lpos, int npaths, int maxlen, const int64_t* cidx,
                       const T* Vt, int64_t ldv, int64_t ncols, const T* L, int64_t ldl, const T* varA, const T* Xs,
                       const T* Cp, int64_t n_pool, int DP, int kernel, double os, double noise, double sm, double* out);
+// paths of 65 .. 256 sites: G = C_PP + sigma_m^2 I - Gram in place for a batch of ppad x ppad blocks (sites packed to the front
+// of each path's ppad entries of cpos, -1 behind them); out[p] = P CONST + 1/2 logdet[p] (NaN where info[p] != 0)
+template <typename T>
+int path_assemble_launch(algp_ctx* c, const int64_t* cpos, int batch, int ppad, const int64_t* cidx, const T* Xs, const T* Cp,
+                         int64_t n_pool, int DP, int kernel, double os, double noise, double sm, T* G);
+int path_finish_launch(algp_ctx* c, const int64_t* cpos, int ppad, int batch, const double* logdet, const int* info, double* out);
 // greedy commit bookkeeping on the device: scale of the appended row, pick record, winner retired, (d_c, scale) out
 template <typename T>
 int commit_finalize_launch(algp_ctx* c, const T* dsrc, int in_train, double ss, double delta, LazyPick* lp_out,

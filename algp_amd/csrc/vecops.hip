@@ -766,6 +766,91 @@ template int path_score_launch<float>(algp_ctx*, const int64_t*, const int64_t*,
                                       int64_t, const float*, int64_t, const float*, const float*, const float*, int64_t, int, int,
                                       double, double, double, double*);
 
+// ---- paths of 65 .. 256 sites (config 5's field rows: up to ~250 sites on a 250 x 200 field, env.py:197-310) -------------
+// The path's posterior block no longer fits LDS: its rows of V^T are gathered into a scratch (gather_rows_kernel, the
+// second-reading transform included), the Gram matrices of a batch of paths are ONE batched MFMA product (gemm.hip), this
+// kernel turns each into G = C_PP + sigma_m^2 I - Gram (identity on the padding) in place, and the blocks are factored
+// as 2 x 2 tiles of 128 by the diagonal-block kernel + two batched tile products (api.hip: score_paths_big).
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void path_assemble_kernel(const int64_t* cpos, int ppad, const int64_t* cidx, const T* Xs, const T* Cp,
+                                                            int64_t n_pool, int kernel, double os, double noise, double sm, T* G) {
+    __shared__ int64_t s_p[256];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int64_t* pc = cpos + (int64_t)blockIdx.x * ppad;
+    if (tid == 0) {
+        int n = 0;
+        while (n < ppad && pc[n] >= 0) ++n;                        // the host packs a path's sites to the front
+        s_n = n;
+    }
+    if (tid < ppad) s_p[tid] = pc[tid] >= 0 ? cidx[pc[tid]] : -1;
+    __syncthreads();
+    const int P = s_n;
+    T* Gp = G + (int64_t)blockIdx.x * ppad * ppad;
+    for (int e = tid; e < ppad * ppad; e += 256) {
+        const int a = e / ppad, b = e - a * ppad;
+        if ((a >> 7) < (b >> 7)) continue;                         // tiles above the diagonal are never read
+        T v;
+        if (a < P && b < P) {
+            const int64_t pa = s_p[a], pb = s_p[b];
+            double cab;
+            if (Cp) {
+                cab = (double)Cp[pa * n_pool + pb];
+            } else {
+                double r2 = 0.0;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    const double df = (double)Xs[pa * DP + d] - (double)Xs[pb * DP + d];
+                    r2 += df * df;
+                }
+                if (kernel == ALGP_KERNEL_RBF) cab = os * kexp(-0.5 * r2);
+                else {
+                    const double r = sqrt(r2) * 1.7320508075688772;
+                    cab = os * (1.0 + r) * kexp(-r);
+                }
+                if (pa == pb) cab += noise;
+            }
+            v = (T)(cab + (a == b ? sm : 0.0) - (double)Gp[e]);
+        } else {
+            v = a == b ? (T)1 : (T)0;
+        }
+        Gp[e] = v;
+    }
+}
+template <typename T>
+int path_assemble_launch(algp_ctx* c, const int64_t* cpos, int batch, int ppad, const int64_t* cidx, const T* Xs, const T* Cp,
+                         int64_t n_pool, int DP, int kernel, double os, double noise, double sm, T* G) {
+    if (batch <= 0) return ALGP_OK;
+    dim3 grid((unsigned)batch), blk(256);
+#define ALGP_PA(DPV)                                                                                                      \
+    hipLaunchKernelGGL((path_assemble_kernel<T, DPV>), grid, blk, 0, c->cur, cpos, ppad, cidx, Xs, Cp, n_pool, kernel, os, noise, sm, G)
+    if (DP == 2) ALGP_PA(2);
+    else if (DP == 4) ALGP_PA(4);
+    else ALGP_PA(8);
+#undef ALGP_PA
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int path_assemble_launch<double>(algp_ctx*, const int64_t*, int, int, const int64_t*, const double*, const double*, int64_t, int, int,
+                                          double, double, double, double*);
+template int path_assemble_launch<float>(algp_ctx*, const int64_t*, int, int, const int64_t*, const float*, const float*, int64_t, int, int,
+                                         double, double, double, float*);
+// out[p] = P CONST + 1/2 log det (NaN where a pivot was not positive)
+__global__ void path_finish_kernel(const int64_t* cpos, int ppad, int batch, const double* logdet, const int* info, double* out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= batch) return;
+    int n = 0;
+    const int64_t* pc = cpos + (int64_t)p * ppad;
+    while (n < ppad && pc[n] >= 0) ++n;
+    out[p] = info[p] != 0 ? NAN : (double)n * ENT_CONST + 0.5 * logdet[p];
+}
+int path_finish_launch(algp_ctx* c, const int64_t* cpos, int ppad, int batch, const double* logdet, const int* info, double* out) {
+    if (batch <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(path_finish_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, c->cur, cpos, ppad, batch, logdet, info, out);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused kernel-GEMV: mu_j = ybar + sum_a k(x_j, x_a) alpha_a, K never materialised (utils.py:301).
 // One wave per output; lanes stride over the train set (coordinates and alpha are L2 resident).

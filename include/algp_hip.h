@@ -205,8 +205,11 @@ int algp_greedy(algp_ctx* ctx, int criterion, double static_std, double mobile_s
  * algp_score_paths: dH_out[p] = H(A u path_p) - H(A) for npaths enumerated paths, where path p adds a mobile reading
  * (noise mobile_std^2) at each of its distinct sites sites[p*maxlen + a] (pool indices, -1 = no site): the reference
  * takes one slogdet of the enlarged covariance per path (agent.py:386-399); here every path is the log-determinant of
- * its <= 64 x 64 posterior block, computed from the rows of V^T that algp_solve_candidates left resident (all sites
- * of all paths must be resident candidates, no pick committed since the solve).  A site that already is a train row
+ * its posterior block of at most 256 x 256 (config 5's paths run along field rows of up to ~250 sites, env.py:197-310),
+ * computed from the rows of V^T that algp_solve_candidates left resident (all sites of all paths must be resident
+ * candidates, no pick committed since the solve): up to 64 distinct sites per path in one LDS kernel, one workgroup per
+ * path; 65 .. 256 with the paths' rows gathered, the Gram matrices as one batched MFMA product and the blocks factored as
+ * 2 x 2 tiles of 128 (batches of paths sized to ~4 GB of scratch).  More than 256 distinct sites: ALGP_ERR_BAD_ARG.  A site that already is a train row
  * (a statically sampled site crossed by the path) receives a second row, which is the same GP as the reference's fused
  * noise (agent.py:100-109) up to the constant log(sigma_s^2 + sigma_m^2)/2 + CONST per such site (the caller's to
  * subtract, see algp_amd/agent.py); the caller leaves out sites that already have a mobile row (no new reading).  The MI criterion's path utility stays with algp_set_entropy. */

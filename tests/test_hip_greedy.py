@@ -484,3 +484,61 @@ def test_score_paths_against_explicit_logdets(dtname, D, kern):
     c.close()
     tol = 1e-9 if dt == np.float64 else 2e-3
     assert np.max(np.abs(got - want)) < tol * max(1.0, np.max(np.abs(want))), np.max(np.abs(got - want))
+
+
+@pytest.mark.parametrize('dtname,kern', [('f64', 'rbf'), ('f64', 'matern'), ('f32', 'rbf')])
+def test_score_paths_of_up_to_256_sites(dtname, kern):
+    """Paths as long as config 5's field rows (agent.py:358-403 scores every enumerated path; env.py:197-310: a path runs along
+    field rows, up to ~250 sites at 250 x 200): 65 .. 256 distinct sites per path go through the batched form -- rows
+    gathered, Gram matrices as one batched MFMA product, blocks factored as 2 x 2 tiles of 128 -- and must equal one NumPy
+    slogdet of the enlarged covariance per path, exactly as the <= 64-site LDS kernel does.  Lengths 65, 128, 129, 200, 256
+    (both padded sizes, both sides of the tile boundary), sites that are train rows already (second rows), a repeated site,
+    an off-field pose; a batch mixing a short path with long ones; 257 distinct sites is an error."""
+    dt = np.float64 if dtname == 'f64' else np.float32
+    rng = np.random.RandomState(3 + (dt == np.float32))
+    n, nA, D = 900, 300, 2
+    X = rng.uniform(0, 30, (n, D))
+    kid = O.KERNEL_RBF if kern == 'rbf' else O.KERNEL_MATERN15
+    hyp = O.Hypers(np.log([2.5, 3.0]), np.log(0.9), np.log(2e-2), kid)
+    A = np.sort(rng.permutation(n)[:nA])
+    varA = rng.choice([0.01, 1.0], nA)
+    c = _hip.Context(dt)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise, kernel=kid)
+    c.set_pool(X)
+    c.set_train(A, np.zeros(nA), varA)
+    c.factorize()
+    c.set_candidates(np.arange(n), prior_includes_noise=True)
+    c.solve_candidates()
+    mobile_std = 0.7
+    others = np.setdiff1d(np.arange(n), A)
+    K = O.kernel_matrix(hyp, X) + hyp.noise * np.eye(n)
+    SA = K[np.ix_(A, A)] + np.diag(varA)
+    ldA = np.linalg.slogdet(SA)[1]
+
+    def build(lengths, width):
+        paths = np.full((len(lengths), width), -1, dtype=np.int64)
+        want = np.zeros(len(lengths))
+        for p, L in enumerate(lengths):
+            sites = list(rng.permutation(others)[:L])
+            for q in range(min(5, L) if p % 2 == 0 else 0):
+                sites[rng.randint(L)] = int(A[rng.randint(nA)])          # crosses train sites: second rows
+            uniq = list(dict.fromkeys(int(s) for s in sites))
+            row = list(sites)
+            if len(row) + 2 <= width:
+                row.append(row[0])                                       # a site crossed twice counts once
+                row.insert(rng.randint(len(row) + 1), -1)                # an off-field pose in the middle
+            paths[p, :len(row)] = row
+            idx = np.r_[A, uniq].astype(int)
+            S = K[np.ix_(idx, idx)] + np.diag(np.r_[varA, np.full(len(uniq), mobile_std ** 2)])
+            want[p] = len(uniq) * O.CONST + 0.5 * (np.linalg.slogdet(S)[1] - ldA)
+        return paths, want
+    tol = 1e-9 if dt == np.float64 else 3e-3
+    for lengths, width in (([65, 128, 100, 7], 140), ([129, 200, 256, 30, 256, 131], 262)):
+        paths, want = build(lengths, width)
+        got = c.score_paths(paths, mobile_std)
+        assert np.max(np.abs(got - want)) < tol * max(1.0, np.max(np.abs(want))), (lengths, np.max(np.abs(got - want)))
+    too_long = np.full((1, 300), -1, dtype=np.int64)
+    too_long[0, :257] = others[:257]
+    with pytest.raises(ValueError):
+        c.score_paths(too_long, mobile_std)
+    c.close()

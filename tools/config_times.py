@@ -98,9 +98,31 @@ def best_path_time():
         t0 = time.perf_counter()
         dH = c.score_paths(sites, 1.0)
         ts.append((time.perf_counter() - t0) * 1e3)
+    out = {'best_path 1000 paths x <=32 sites, N=10000': dict(score_paths_ms=float(np.median(ts)), finite=bool(np.all(np.isfinite(dH))))}
+    # paths as long as config 5's field rows: 1 000 paths x 200 distinct sites (the 65 .. 256-site form: rows gathered, one
+    # batched MFMA product for the Gram matrices, 2 x 2 tiles of 128 per block); sites drawn from the unsampled 2 500 and,
+    # for every second path, 20 train sites (second rows)
+    sites = np.full((1000, 200), -1, dtype=np.int64)
+    for p in range(1000):
+        row = rng.permutation(rest)[:200]
+        if p % 2:
+            row[:20] = A[rng.permutation(len(A))[:20]]
+        sites[p] = row
+    c.score_paths(sites, 1.0)
+    ts = []
+    for rep in range(5):
+        c.sync()
+        t0 = time.perf_counter()
+        dH = c.score_paths(sites, 1.0)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(ts))
+    flops = 1000 * 3 * 2.0 * 128 * 128 * 10112            # the Gram products: 3 lower tiles of 128 x 128 x Npad per path
+    out['best_path 1000 paths x 200 sites, N=10000'] = dict(score_paths_ms=ms, finite=bool(np.all(np.isfinite(dH))),
+                                                            gram_tflops_over_whole_call=flops / (ms * 1e-3) / 1e12,
+                                                            gathered_bytes=1000 * 256 * 10112 * 8)
     c.close()
-    return 'best_path 1000 paths x <=32 sites, N=10000', dict(score_paths_ms=float(np.median(ts)), finite=bool(np.all(np.isfinite(dH))))
+    return out
 
 
 if 'best_path' in sys.argv[1:]:
-    print(json.dumps(dict([best_path_time()]), indent=1))
+    print(json.dumps(best_path_time(), indent=1))

@@ -2,6 +2,9 @@
 GEMM launch, in enqueue order) by dispatch order and prints, for the candidate solve's GEMM launches (class 2), a table by
 launch shape (tiles x K): calls, summed duration, TFLOP/s executed -- and the sum of their durations per solve, the figure
 bench.py's roofline.serial_kernel_frac is formed from with HIP events.
+Also printed, per solve, the SPAN of its launches -- first dispatch start to last dispatch end in the trace -- beside the sum of
+their durations: with the solve's row chunks on three streams the launches overlap, the span is the solve's wall time as the
+profiler saw it, the figure bench.py's roofline.achieved is formed from with HIP events (wall_ms_all_launches / steps).
 usage: python tools/trace_shapes.py <kernel_trace.csv> <launch_log.txt> <solves in the trace> [<bench line .json>]"""
 import csv
 import json
@@ -16,7 +19,7 @@ if len(rows) != len(launches):
     raise SystemExit('trace holds %d GEMM dispatches, the launch log %d lines' % (len(rows), len(launches)))
 shape = defaultdict(lambda: [0, 0.0, 0.0])
 tot_ns, tot_fl, n2 = 0, 0.0, 0
-first, last = None, None
+solve_rows = []
 for r, rec in zip(rows, launches):
     klass, m, n, k, lower, batch, ktri, es = rec[:8]
     kcut = rec[8] if len(rec) > 8 else 0
@@ -37,6 +40,7 @@ for r, rec in zip(rows, launches):
     tot_ns += ns
     tot_fl += fl
     n2 += 1
+    solve_rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), ns))
 print('candidate-solve GEMM launches (class GEMM_TRSM): %d in %d solves' % (n2, nsolves))
 print('%10s %7s %7s %11s %10s' % ('tiles', 'K', 'calls', 'sum ms', 'TFLOP/s'))
 for (tiles, k), (calls, ms, fl) in sorted(shape.items(), key=lambda kv: -kv[1][1]):
@@ -54,3 +58,31 @@ if len(sys.argv) > 4:
     print('  -> the launches back to back: %.1f TFLOP/s algorithmic = %.3f of %.1f by the trace, %.3f by the events'
           % (rf['algorithmic_flops_per_step'] / (per * 1e-3) / 1e12, rf['algorithmic_flops_per_step'] / (per * 1e-3) / 1e12 / rf['peak'], rf['peak'],
              rf['algorithmic_flops_per_step'] / (ev * 1e-3) / 1e12 / rf['peak']))
+
+# per solve: span (first start -> last end) beside the sum of the launch durations
+if n2 % nsolves == 0 and n2 > 0:
+    per_solve = n2 // nsolves
+    spans, sums, streams = [], [], set(r['Stream_Id'] for r in rows) if rows and 'Stream_Id' in rows[0] else set()
+    for q in range(nsolves):
+        grp = solve_rows[q * per_solve:(q + 1) * per_solve]
+        spans.append((max(e for _, e, _ in grp) - min(st for st, _, _ in grp)) * 1e-6)
+        sums.append(sum(ns for _, _, ns in grp) * 1e-6)
+    print('per solve, span of its launches (first start -> last end) / sum of their durations, ms:')
+    print('  ' + '  '.join('%.2f / %.2f' % (a, b) for a, b in zip(spans, sums)))
+    med = sorted(spans)[len(spans) // 2]
+    print('median span %.2f ms over %d solves (%d GEMM streams in the trace); sum / span = %.2f'
+          % (med, nsolves, len(streams), sorted(sums)[len(sums) // 2] / med))
+    if len(sys.argv) > 4:
+        b = json.load(open(sys.argv[4]))
+        rf = b['roofline']
+        wall = rf['wall_ms_all_launches'] / b['steps']
+        # the bench's K timed steps are solves 1 + warmup .. warmup + K of the process (its stage timers bracket exactly them)
+        w0 = b.get('warmup', 0)
+        timed = spans[w0:w0 + b['steps']] if len(spans) >= w0 + b['steps'] else spans
+        tm = sum(timed) / len(timed)
+        print('bench line of the same process: wall time of the solve by HIP events %.2f ms (roofline.wall_ms_all_launches / steps); '
+              'mean span of the same %d solves in the trace %.2f ms -> trace / events = %.3f'
+              % (wall, len(timed), tm, tm / wall))
+        print('  -> N^2 M / span = %.1f TFLOP/s = %.3f of %.1f by the trace; the line says %.3f'
+              % (rf['algorithmic_flops_per_step'] / (tm * 1e-3) / 1e12, rf['algorithmic_flops_per_step'] / (tm * 1e-3) / 1e12 / rf['peak'],
+                 rf['peak'], rf['frac']))
