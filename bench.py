@@ -732,6 +732,101 @@ def strong_emulation(ctx, _hip, res, args):
     return out
 
 
+def loop_mode(args, world, rank, local_rank, dist, torch):
+    """`bench.py --loop K [--gpus N]`: BASELINE config 5's active-learning loop itself (reference agent.py:125-229) on N real
+    ranks -- every rank replicates the factor of the growing train set and owns 1/N of the candidates (sharded.ShardLink,
+    strided owner map); per planning step: factor update with the new train sites' rows arriving in the row exchange
+    (algp_comm_set_owners), the new columns of the rank's rows of V^T, 4 picks through algp_greedy_sharded; then the picks
+    + 26 mobile readings join the train set.  One from-scratch step, then K incremental ones, timed per step between
+    barriers on rank 0 and as a whole (max over ranks).  Prints ONE JSON line (metric: ms per incremental step)."""
+    from algp_amd import _hip
+    from algp_amd.sharded import ShardLink
+    rng = np.random.RandomState(5)
+    R, C = args.loop_field
+    grid, field, pool = _c5_field(rng, R, C, args.cand)
+    N0, M, n = len(grid), args.cand, len(grid) + args.cand
+    ctx = _hip.Context(np.float64, device=local_rank)
+    ctx.set_hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
+    ctx.set_pool(pool)
+    link, transport = None, 'none (one rank)'
+    if world > 1:
+        if args.backend == 'nccl':
+            uid = [_hip.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            link = ShardLink(rank, world, unique_id=uid[0])
+            transport = 'RCCL inside libalgp_hip.so (algp_comm_init): one all-gather per pick + agreement word and row all-gather per step'
+        else:
+            def gloo_gather(send):
+                t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+                out = torch.empty(world * len(send), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, t)
+                return out.numpy().tobytes()
+            link = ShardLink(rank, world, all_gather=gloo_gather)
+            transport = 'gloo all-gather supplied by the caller (algp_comm_init_host)'
+        link.attach(ctx, n)
+        mine = link.mine(n)
+        mine = mine[mine >= N0]
+    else:
+        mine = np.arange(N0, n)
+    idx = np.arange(N0)
+    var = np.where(rng.uniform(size=N0) < 0.5, 0.01, 1.0)
+    y = np.maximum(field + rng.standard_normal(N0) * np.sqrt(var), 0.0)
+    static = np.zeros(n, bool)
+    static[:N0] = var == 0.01
+    cidx = np.arange(N0, n)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+    times, picks_log = [], []
+    t_all = None
+    for s in range(args.loop + 1):
+        if s == 1:
+            barrier()
+            t_all = time.perf_counter()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.set_train(idx, y, var)
+        ctx.factorize(incremental=True)
+        ctx.set_candidates(mine, prior_includes_noise=True)
+        ctx.solve_candidates(incremental=True, alive=~static[mine])
+        if world > 1:
+            pk = [int(p) for p in ctx.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, args.picks)]
+        else:
+            pk = [int(p) for p in ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, args.picks)]
+        barrier()
+        times.append((time.perf_counter() - t0) * 1e3)
+        picks_log.append(pk)
+        static[pk] = True
+        mob = cidx[rng.permutation(M)[:26]]
+        mob = mob[~np.isin(mob, idx) & ~np.isin(mob, pk)]
+        idx = np.r_[idx, pk, mob]
+        var = np.r_[var, np.full(len(pk), 0.01), np.full(len(mob), 1.0)]
+        y = np.r_[y, rng.uniform(0, 1, len(pk) + len(mob))]
+    barrier()
+    total = time.perf_counter() - t_all
+    if dist is not None:
+        t = torch.tensor([total], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total = float(t.item())
+    out = None
+    if rank == 0:
+        inc = np.array(times[1:])
+        out = {'metric': 'active-learning loop, ms per planning step (config 5: factor update + new columns of V^T + %d picks)' % args.picks,
+               'value': float(np.median(inc)), 'unit': 'ms/step', 'n_gpus': world, 'steps': args.loop, 'warmup': 1,
+               'ms_per_step': 1e3 * total / args.loop, 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None,
+               'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': '%d-point MoG field (%d x %d) growing by %d picks + 26 mobile readings per step, %d candidates '
+                                      'sharded over %d rank(s), entropy criterion' % (N0, R, C, args.picks, M, world),
+                          'n_train_first_last': [N0, int(len(idx))], 'candidates_per_gpu': int(len(mine)), 'collective': transport},
+               'from_scratch_step_ms': times[0], 'step_ms_p95': _pct(inc, 95), 'step_ms_max': float(inc.max()),
+               'loop_total_s': total, 'picks_last_step': picks_log[-1],
+               'row_exchanges': ctx.counter(3), 'fallbacks_to_the_triangular_solve': ctx.counter(4), 'roofline': None, 'cpu_baseline': None}
+    ctx.close()
+    return out
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` launched plainly: start the N ranks as a CHILD `python -m torch.distributed.run`
     (never an exec, and before this process has imported torch or touched HIP), relay rank 0's JSON line, exit with the
@@ -780,6 +875,9 @@ def main():
                     help='abi: the all-gather inside the library (algp_greedy_sharded; RCCL with --backend nccl, the caller\'s '
                          'gloo all-gather handed to algp_comm_init_host with --backend gloo); torch: ShardedGreedy over '
                          'torch.distributed (the cross-check)')
+    ap.add_argument('--loop', type=int, default=0, help='K > 0: run config 5\'s active-learning loop for K incremental steps on the --gpus ranks '
+                    'instead of the config-4 step (candidates sharded, factor replicated; see loop_mode)')
+    ap.add_argument('--loop-field', type=lambda v: tuple(int(x) for x in v.split('x')), default=(250, 200), help='RxC of the loop\'s field (default 250x200 = 50 000 sites)')
     ap.add_argument('--cpu-train', type=int, default=6000)
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r04_traffic_pmc.json'))
     args = ap.parse_args()
@@ -812,6 +910,18 @@ def main():
         else:
             dist.init_process_group('gloo')
 
+    if args.loop > 0:
+        res = loop_mode(args, world, rank, local_rank, dist, torch)
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            print(json.dumps(res))
+            sys.stdout.flush()
+            os.dup2(2, 1)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     from algp_amd import _hip
     from algp_amd.sharded import LocalComm, ShardedGreedy, TorchComm
 
@@ -830,7 +940,7 @@ def main():
                     uid = [_hip.Context.comm_unique_id() if rank == 0 else None]
                     dist.broadcast_object_list(uid, src=0)
                     ctx.comm_init(world, rank, uid[0])
-                    collective = 'algp_greedy_sharded: ncclAllGather of (utility, pool index, status) inside libalgp_hip.so'
+                    collective = 'algp_greedy_sharded: ncclAllGather of (utility, pool index, status, statistic + that candidate\'s row of V^T) inside libalgp_hip.so'
                 else:
                     def gloo_gather(send):
                         t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
@@ -1023,7 +1133,7 @@ def main():
                        'criterion': 'entropy (agent.py:125 default); the MI criterion (agent.py:330-339) needs pool-wide inverse '
                                     'diagonals and does not shard: it is timed in extra.mi_criterion',
                        'n_train': N, 'candidates_per_gpu': res['M0'], 'candidates_total': total_c,
-                       'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + pool index + status)' % world,
+                       'parallelism': 'candidate shards x%d, one all-gather per pick (each rank\'s best utility + pool index + status + statistic and that candidate\'s row of V^T)' % world,
                        'collective': collective},
             'roofline': roof,
             'cholesky': {'fit_ms': fit_ms, 'tflops_n3_over_3_per_fit_ms': chol_tf, 'kernel': 'chol_dag_kernel (one launch)',

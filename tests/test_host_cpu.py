@@ -61,6 +61,69 @@ def test_partition():
             assert max(h - l for l, h in p) - min(h - l for l, h in p) <= 1
 
 
+def test_shard_link_owner_maps():
+    """sharded.ShardLink: the owner map handed to algp_comm_set_owners and the rank's share of the pool (host logic of the
+    sharded active-learning loop).  Every site has exactly one owner, the shares are balanced, 'contiguous' is the
+    partition of SURVEY 8(e), 'strided' spreads neighbouring sites (a path's readings) over all owners."""
+    from algp_amd.sharded import ShardLink, partition
+    for n in (1, 7, 360, 100001):
+        for w in (2, 3, 8):
+            for layout in ('strided', 'contiguous'):
+                links = [ShardLink(r, w, all_gather=lambda b: b, layout=layout) for r in range(w)]
+                own = links[0].owners(n)
+                assert own.dtype == np.int32 and len(own) == n and own.min() >= 0 and own.max() < w
+                assert all(np.array_equal(l.owners(n), own) for l in links)           # the same map on every rank
+                shares = [l.mine(n) for l in links]
+                assert np.array_equal(np.sort(np.concatenate(shares)), np.arange(n))  # a partition of the pool
+                assert max(map(len, shares)) - min(map(len, shares)) <= 1
+                for r, sh in enumerate(shares):
+                    assert np.all(own[sh] == r) and np.all(np.diff(sh) > 0)
+                if layout == 'contiguous':
+                    assert [(int(sh[0]), int(sh[-1]) + 1) if len(sh) else None for sh in shares] == \
+                        [(lo, hi) if hi > lo else None for lo, hi in partition(n, w)]
+                elif n >= 4 * w:
+                    run = np.arange(n // 2, n // 2 + 2 * w)                          # 2w neighbouring sites: every rank owns two
+                    assert np.all(np.bincount(own[run], minlength=w) == 2)
+    with pytest.raises(ValueError):
+        ShardLink(0, 2)                                                               # no transport
+    with pytest.raises(ValueError):
+        ShardLink(0, 2, unique_id=b'x' * 128, all_gather=lambda b: b)                 # two transports
+    with pytest.raises(ValueError):
+        ShardLink(0, 2, all_gather=lambda b: b, layout='random')
+
+
+def test_sharded_pairs_tie_break_is_the_smaller_position():
+    """Equal utilities on several ranks: the winner is the smaller global position whichever rank offers it (np.argmax's
+    first maximum in pool order, agent.py:349) -- the rule first_max_kernel applies on the device (comm.hip)."""
+    from algp_amd.sharded import ShardedGreedy
+
+    class Comm(object):
+        rank, world_size = 0, 3
+
+        def __init__(self, pairs):
+            self.pairs = np.array(pairs, dtype=np.float64)
+
+        def all_gather_pairs(self, value, position):
+            return self.pairs
+
+    class Backend(object):
+        M = 2
+        committed = None
+
+        def best_candidate(self, criterion, a, b):
+            return 1, 11, 0.5
+
+        def commit_pick(self, idx, a, b):
+            self.committed = idx
+    cand = np.arange(100, 106)
+    for pairs, want in (([[0.5, 5], [0.5, 2], [0.25, 0]], 102), ([[0.5, 1], [0.5, 2], [0.5, 4]], 101),
+                        ([[-np.inf, -1], [0.1, 3], [0.1, 2]], 102)):
+        b = Backend()
+        sg = ShardedGreedy(b, Comm(pairs), cand)
+        w, v = sg.step(0, 0.1, 1.0)
+        assert (w, b.committed) == (want, want), (pairs, w)
+
+
 WORKER = r'''
 import os, sys
 import numpy as np
@@ -145,13 +208,20 @@ dist.destroy_process_group()
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def test_sharded_greedy_two_ranks_gloo(tmp_path):
     import subprocess
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'repo': REPO})
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29517', str(script)],
+                          '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'SHARDED_OK' in out.stdout

@@ -57,12 +57,19 @@ dist.destroy_process_group()
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def test_two_ranks_shard_one_gpu(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'repo': REPO})
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29571', str(script)],
+                          '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'MULTIPROC_OK' in out.stdout

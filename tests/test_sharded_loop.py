@@ -210,3 +210,30 @@ def test_twenty_incremental_steps_on_two_ranks_equal_the_one_rank_loop(tmp_path,
 
 def test_agent_mission_loop_sharded_over_two_ranks(tmp_path):
     _run(tmp_path, AGENT_WORKER, {}, 'SHARDED_AGENT_OK')
+
+
+def _bench(args, env_extra=None):
+    import json
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_loop_mode_two_ranks_on_one_card_equals_one_rank():
+    """`bench.py --loop K --gpus 2` (what the driver can run on a node: config 5's loop on real ranks) rehearsed on one card
+    over gloo at a reduced size: same picks as the one-rank loop at the last step, every factor update of the sharded run
+    went through the row exchange, none fell back."""
+    common = ['--loop', '6', '--loop-field', '60x50', '--cand', '9000']
+    one = _bench(['--gpus', '1'] + common)
+    two = _bench(['--gpus', '2', '--backend', 'gloo'] + common, {'ALGP_BENCH_DEVICE': '0'})
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and two['steps'] == 6
+    assert two['picks_last_step'] == one['picks_last_step']
+    assert two['row_exchanges'] == 6 and two['fallbacks_to_the_triangular_solve'] == 0
+    assert two['config']['candidates_per_gpu'] == 4500 and one['config']['candidates_per_gpu'] == 9000
+    assert two['value'] > 0 and two['higher_is_better'] is False
