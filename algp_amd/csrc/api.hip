@@ -342,6 +342,7 @@ struct Impl {
         bool done;
         T* inv_out = nullptr;      // mode 2: S^-1 = P P^T (lower tiles, ld = mpad) is enqueued on the helper stream right behind
         bool inv_enqueued = false; // the launch, beside the substitutions and read-backs that follow on the main stream
+        int64_t z_row = -1;        // mode 1: this (padding) row of P holds y - ybar: z^T = (y - ybar)^T L^-T comes out of the launch too
     };
     static bool panel_fits(int64_t npad, int64_t mpad) {
         const int64_t nt = npad / NB, mt = mpad / NB;
@@ -689,11 +690,12 @@ struct Impl {
         }
         prof_span_end(c);
         ALGP_TRY(frc);
-        return finish_factor(c, keep, p0, ld_total);
+        T* z_src = (panel && panel->done && panel->mode == 1 && panel->z_row >= 0) ? panel->P + panel->z_row * panel->ldp : nullptr;
+        return finish_factor(c, keep, p0, ld_total, z_src);
     }
 
     // after L (rows >= keep new) is in place: log det, z = L^-1 (y - ybar), y0' S^-1 y0, bookkeeping
-    static int finish_factor(algp_ctx* c, int64_t keep, int64_t p0, double ld_total) {
+    static int finish_factor(algp_ctx* c, int64_t keep, int64_t p0, double ld_total, T* z_src = nullptr) {
         const int64_t N = c->N, Npad = c->Npad, ld = c->Lld;
         c->logdet = ld_total;
         if (keep > 0) {
@@ -718,6 +720,12 @@ struct Impl {
             c->uw_rows = N;
             c->uw_stable = std::min(c->uw_stable, ku);
             c->fact_y = c->train_y_host;
+        } else if (z_src) {
+            // z rode along with the factorisation as a row of the candidates' panel (fit_and_solve): no substitution launch
+            ALGP_HIP(hipMemcpyAsync(c->z.p, z_src, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
+            ALGP_HIP(hipMemsetAsync(z_src, 0, sizeof(T) * Npad, c->stream));       // the row is a padding row of V^T again
+            c->uw_rows = 0;
+            c->uw_stable = 0;
         } else {
             ALGP_HIP(hipMemcpyAsync(c->z.p, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
             ALGP_TRY(trsv_forward<T>(c, p(c->L), Npad, ld, p(c->invD), p(c->z)));
@@ -1057,8 +1065,19 @@ struct Impl {
         SolvePlan pl;
         ALGP_TRY(solve_prepare(c, 0, pl));                           // B^T is in place before the launch that consumes it
         Panel pn{p(c->Vt), c->ldv, c->Mpad, 1, false};
+        // a spare (padding) row of the candidates' last tile carries y - ybar through the launch: z = L^-1 (y - ybar) comes out
+        // as that row of P L^-T, and the forward substitution behind the launch (0.41 ms at N = 10 000, with the machine
+        // idle) falls away ($ALGP_Z_IN_PANEL=0: the substitution)
+        static const bool z_on = !(getenv("ALGP_Z_IN_PANEL") && atoi(getenv("ALGP_Z_IN_PANEL")) == 0);
+        if (z_on && c->M < c->Mpad) {
+            pn.z_row = c->M;
+            ALGP_HIP(hipMemcpyAsync(p(c->Vt) + c->M * c->ldv, c->y0.p, sizeof(T) * c->Npad, hipMemcpyDeviceToDevice, c->stream));
+        }
         ALGP_TRY(factorize(c, 0, &pn));
-        if (!pn.done) ALGP_TRY(solve_run(c, pl));
+        if (!pn.done) {
+            if (pn.z_row >= 0) ALGP_HIP(hipMemsetAsync(p(c->Vt) + pn.z_row * c->ldv, 0, sizeof(T) * c->Npad, c->stream));
+            ALGP_TRY(solve_run(c, pl));
+        }
         return solve_finish(c, 0, nullptr, pl);
     }
 

@@ -763,10 +763,25 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
             if (!solve_only)
                 for (int i = j; i < nt; ++i)
                     if (!single || i > k + 2) upd(i, j, k0, k1);
-            if (single) return;
+        };
+        // The panel's far updates in batches of their own: a panel row gates nothing but itself (its own TU recurrence, 79
+        // steps of ~90 us, is far shorter than the launch), so its batches are as long as the columns allow -- sixteens (K = 2048)
+        // from column 0, at most one eight and one four next to the near window -- where the factor's
+        // rows keep the shorter batches that let the chain run ahead.  In the folded launch of config 4's rank share (79 + 98
+        // tile rows) 41 % of the workgroup time sat in panel batches of K = 512 / 1024 at 34.1 / 33.0 us per 128-step against
+        // 31.8 for K = 2048 (tools/dag_test.hip 79 3 d 98): one read + write of the tile and one ticket / wait / publish per batch.
+        auto panel_far = [&](int j) {
+            const int kf = batched_until(j, W);
+            if (k >= kf) return;
+            const int pf8 = 8 * (kf / 8), pf16 = 16 * (pf8 / 16);
+            int k0 = -1;
+            if (k < pf16) { if ((k + 1) % 16 == 0) k0 = k - 15; }     // (a task polls 1 + 2 n <= 64 version words: n <= 31)
+            else if (k < pf8) { if ((k + 1) % 8 == 0) k0 = k - 7; }
+            else if ((k + 1) % 4 == 0) k0 = k - 3;
+            if (k0 < 0) return;
             for (int e = 0; e < mt; ++e) {
                 const int ps = shape.pstart(e);
-                if (ps < k1) upd(nt + e, j, std::max(k0, ps), k1);
+                if (ps < k + 1) upd(nt + e, j, std::max(k0, ps), k + 1);
             }
         };
         // A panel row is on nobody's critical path: the single steps of its tile (i, j) -- columns [kf, j-1), one to four of
@@ -781,6 +796,7 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
         };
         if (k + 2 < nt) panel_near(k + 2);
         for (int j = k + 1; j < nt; ++j) {
+            if (mt > 0) panel_far(j);
             const int kf = batched_until(j, W);
             if (k >= kf) {
                 if (j != k + 1) upd_rows(j, k, k + 1, true);                 // single step (column k+1 went with the TRSM: DAG_TU)

@@ -619,6 +619,7 @@ def strong_emulation(ctx, _hip, res, args):
     the first and the last rank of each n.  Left out: the wire time of RCCL's all-gather (n x 80 KB per pick) and skew
     between ranks; the host transport used here costs two stream synchronisations and ~0.7 MB of PCIe traffic per pick
     instead, plus the Python callback."""
+    import ctypes
     import struct
     from algp_amd.sharded import partition
     w0, N0, total = res['w'], res['N'], res['total_c']
@@ -654,39 +655,30 @@ def strong_emulation(ctx, _hip, res, args):
                 lo, hi = parts[r]
                 share = allc[lo:hi]
                 owners = [next(s for s, (a, b) in enumerate(parts) if a <= (p - N0) < b) for p in picks]
-                state = {'q': 0, 'pb': None, 'tmpl': None, 'calls': 0}
+                state = {'q': 0, 'calls': 0}
+                absent = struct.pack('<4d', float('-inf'), -1.0, 0.0, 0.0)
 
-                def build(pb):
-                    absent = struct.pack('<4d', float('-inf'), -1.0, 0.0, 0.0)
-                    tm = []
-                    for q in range(k):
-                        buf = bytearray(n * pb)
-                        for s_ in range(n):
-                            buf[s_ * pb:s_ * pb + 32] = absent
-                        if owners[q] != r:
-                            row, d = rows[q]
-                            o = owners[q] * pb
-                            buf[o:o + 24] = struct.pack('<3d', util[q], float(picks[q]), 0.0)
-                            buf[o + 24:o + 24 + es] = np.asarray([d], dtype=ctx.dtype).tobytes()
-                            rb = row.tobytes()
-                            buf[o + 32:o + 32 + len(rb)] = rb
-                        tm.append(buf)
-                    return tm
-
-                def fn(send, r=r, state=state, build=build):
-                    pb = len(send)
-                    if state['pb'] != pb:
-                        state['pb'], state['tmpl'] = pb, build(pb)
+                def fn(send, recv, pb, r=r, state=state):
+                    # raw form of the callback: the library's pinned staging itself.  (Round 4 went through Python bytes objects:
+                    # ~1.5 ms of copies per step that belong to neither the product nor a real transport.)
                     state['calls'] += 1
                     q = min(state['q'], k - 1)
-                    buf = state['tmpl'][q]
-                    buf[r * pb:(r + 1) * pb] = send
-                    if struct.unpack_from('<d', send, 16)[0] == 0.0:     # a settled round: the next call is the next pick
+                    for s_ in range(n):
+                        if s_ != r:
+                            ctypes.memmove(recv + pb * s_, absent, 32)
+                    if owners[q] != r:
+                        row, d = rows[q]
+                        o = recv + pb * owners[q]
+                        ctypes.memmove(o, struct.pack('<3d', util[q], float(picks[q]), 0.0), 24)
+                        ctypes.memmove(o + 24, np.asarray([d], dtype=ctx.dtype).tobytes(), es)
+                        ctypes.memmove(o + 32, row.ctypes.data, row.nbytes)
+                    ctypes.memmove(recv + pb * r, send, pb)
+                    if struct.unpack('<d', ctypes.string_at(send + 16, 8))[0] == 0.0:     # a settled round: the next call is the next pick
                         state['q'] += 1
-                    return bytes(buf)
+                    return 0
 
                 ctx.set_candidates(share, prior_includes_noise=True)
-                ctx.comm_init_host(n, r, fn)
+                ctx.comm_init_host(n, r, fn, raw=True)
                 try:
                     def one():
                         state['q'] = 0
@@ -1171,7 +1163,7 @@ def main():
                                'each winner).  ms_per_step = the slower of the two ranks; speedup_vs_1 = this run\'s ms_per_step / that; '
                                'scoring_only_* subtract the replicated fit timed on its own (fit_alone_ms) from the rank\'s step and '
                                'stage_ms_per_step.cholesky from the one-GPU step.  Not in it: RCCL\'s wire time for n x 80 KB per pick (the '
-                               'host transport\'s two synchronisations, PCIe copies and Python callback are in it instead) and skew between '
+                               'host transport\'s two synchronisations, PCIe staging copies and a raw Python callback are in it instead) and skew between '
                                'ranks.  Up to 51 200 rows the fit and the solve are ONE task-list launch (fit_and_solve_in_one_launch).')
                 out['strong_emulation'] = emu
         if weak is not None:
