@@ -857,14 +857,25 @@ struct Impl {
             // $ALGP_TAIL_COLS=0: the 128-column blocks as before.  Small problems keep them too (nothing to gain).
             const bool tail_on = !(getenv("ALGP_TAIL_COLS") && atoi(getenv("ALGP_TAIL_COLS")) == 0);    // read per call: tests flip it
             if (tail_on && p0 >= 2048 && Mpad >= 2048 && c->cur == c->stream) {
-                const int64_t k16 = p0 / 16 * 16, c1 = round_up(N, 16);
+                // exactly the appended rows [p0, N) when there are at most 64 of them (tail.hip handles any first column; the
+                // epilogue's inverse is that of a window of L around the range, solve_run); $ALGP_TAIL_EXACT=0: from the
+                // 16-column boundary below p0 to the one above N (rounds 3-4: 48 columns of MFMA work for 30 new rows)
+                const bool exact_on = !(getenv("ALGP_TAIL_EXACT") && atoi(getenv("ALGP_TAIL_EXACT")) == 0);
+                const bool exact = exact_on && N > p0 && N - p0 <= 64;
+                const int64_t k16 = exact ? p0 : p0 / 16 * 16, c1 = exact ? N : round_up(N, 16);
                 int n = 0;
                 bool ok = c1 > k16;
+                if (exact) {
+                    pl.seg_c0[0] = p0;
+                    pl.seg_w[0] = (int)(N - p0);
+                    pl.seg_window = true;
+                    n = 1;
+                }
                 // at most 64 new columns: ONE pass over V^T even where they straddle two 128-column blocks of the factor (the
                 // epilogue then takes the inverse of the 128 x 128 window of L at (k16, k16), solve_run); $ALGP_TAIL_STRADDLE=0: a
                 // pass per block as before (16 ms instead of 9.5 for the 40 GB of config 5)
                 const bool straddle_on = !(getenv("ALGP_TAIL_STRADDLE") && atoi(getenv("ALGP_TAIL_STRADDLE")) == 0);
-                if (ok && straddle_on && c1 - k16 <= 64 && k16 / NB != (c1 - 1) / NB && k16 + NB <= Npad) {
+                if (ok && !exact && straddle_on && c1 - k16 <= 64 && k16 / NB != (c1 - 1) / NB && k16 + NB <= Npad) {
                     pl.seg_c0[0] = k16;
                     pl.seg_w[0] = (int)(c1 - k16);
                     pl.seg_window = true;
@@ -960,11 +971,14 @@ struct Impl {
                         sizeof(T) * (double)Mpad * (double)Npad);
         int trc = ALGP_OK;
         if (pl.nseg > 0 && pl.seg_window) {
+            // the inverse of a 128 x 128 window of L that contains the range (inv(D)[S, S] = inv(D[S, S]) for any diagonal range S of
+            // a lower-triangular D): from the range's first column, or -- near the end of the factor -- the last 128 rows
+            const int64_t w0 = std::min<int64_t>(pl.seg_c0[0], Npad - NB), o = pl.seg_c0[0] - w0;
             trc = ensure(c, c->tailE, sizeof(T) * NB * NB);
-            if (trc == ALGP_OK) trc = trinv_diag_launch<T>(c, p(c->L) + pl.seg_c0[0] * c->Lld + pl.seg_c0[0], c->Lld, p(c->tailE));
+            if (trc == ALGP_OK) trc = trinv_diag_launch<T>(c, p(c->L) + w0 * c->Lld + w0, c->Lld, p(c->tailE));
             if (trc == ALGP_OK)
                 trc = tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad, (const T*)nullptr,
-                                          pl.seg_c0[0], pl.seg_w[0], p(c->tailE));
+                                          pl.seg_c0[0], pl.seg_w[0], p(c->tailE) + o * NB + o);
         } else if (pl.nseg > 0) {
             for (int q = 0; q < pl.nseg && trc == ALGP_OK; ++q)
                 trc = tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad,
@@ -1002,8 +1016,12 @@ struct Impl {
             }
             T* acc = p(c->acc3);
             T* tmp = acc + 3 * Mpad;
-            for (int64_t j : pl.became_unit)                              // their kept columns were zeroed above
-                for (int q = 0; q < 3; ++q) ALGP_HIP(hipMemsetAsync(acc + q * Mpad + j, 0, sizeof(T), c->stream));
+            if (!pl.became_unit.empty()) {                                // their kept columns were zeroed above: one launch
+                const size_t nb = pl.became_unit.size();                  // (three 8-byte memsets per row before: ~5 us each)
+                ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * nb));
+                ALGP_HIP(hipMemcpyAsync(c->auxIdx.p, pl.became_unit.data(), sizeof(int64_t) * nb, hipMemcpyHostToDevice, c->stream));
+                ALGP_TRY(zero_rows3_launch<T>(c, acc, Mpad, (const int64_t*)c->auxIdx.p, (int64_t)nb));
+            }
             const int64_t fin = N / NB * NB;                              // column blocks no later append can touch
             if (fin > c->acc_cols)
                 ALGP_TRY(rows_reduce3_launch<T>(c, p(c->Vt), M, ldc, c->acc_cols, fin, p(c->uvec), p(c->wvec), acc, Mpad, 1));
@@ -2016,7 +2034,7 @@ void algp_destroy(algp_ctx* c) {
     DevBuf* bufs[] = {&c->Xs, &c->Xraw, &c->Cp, &c->Aidx, &c->yA, &c->varA, &c->y0, &c->L, &c->invD, &c->z, &c->alpha,
                       &c->scal, &c->Cidx, &c->ckind, &c->cextra, &c->Vt, &c->dstat, &c->mu, &c->alive, &c->scores,
                       &c->lrow, &c->remote, &c->commbuf, &c->tvec, &c->amax, &c->prevrows, &c->fresh, &c->lazypicks, &c->yraw, &c->uvec, &c->wvec, &c->acc3, &c->rowstat, &c->inv512, &c->inv512_scr, &c->trsm_tmp, &c->splitk, &c->dag_state, &c->dag_stats, &c->trsv_ctrl, &c->miXbar, &c->miXall, &c->miDP, &c->miDQ, &c->miPos, &c->miU, &c->miW, &c->miCol, &c->miH, &c->auxA, &c->auxInv, &c->auxW, &c->auxIdx,
-                      &c->auxVar, &c->auxD, &c->hostStage, &c->rowx, &c->tailE, &c->tailPart};
+                      &c->auxVar, &c->auxD, &c->hostStage, &c->rowx, &c->tailE, &c->tailPart, &c->ldpart};
     for (DevBuf* b : bufs) release(c, *b);
     dag_release(c);
     comm_destroy(c);

@@ -157,6 +157,7 @@ struct algp_ctx {
     algp::DevBuf acc3;
     algp::DevBuf rowstat;                // per column tile of V^T: row sums of v^2 and v z left by the solve's own launches
     algp::DevBuf splitk;                 // partial products of split-K launches (skinny solves)
+    algp::DevBuf ldpart;                 // logdiag_kernel's per-wave partial sums
     algp::DevBuf tailPart;               // tail.hip: partial accumulators of the k-split form
     algp::DevBuf tailE;                  // tail.hip: inverse of the 128 x 128 window of L at the first new column (a range that straddles two blocks)
     algp::DevBuf inv512, inv512_scr, trsm_tmp;   // candidate solve: explicit inverses of the factor's 512-column blocks, their scratch, mpad x 512

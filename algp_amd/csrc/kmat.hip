@@ -163,7 +163,13 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> a) {
             const int64_t cd = r + a.ident_shift;
             if (cd >= c0 && cd < cend && (cd >= a.cols || r >= a.rows)) o[(int)(cd - c0)] = (T)1;
         }
-        *reinterpret_cast<vec_t*>(a.out + r * a.ldo + c0) = o;
+        if (cend <= a.cols_pad) {
+            *reinterpret_cast<vec_t*>(a.out + r * a.ldo + c0) = o;
+        } else {                                                   // a column count that is no multiple of VEC (a window that starts
+#pragma unroll                                                     // at an arbitrary column of V^T): never store beyond it
+            for (int v = 0; v < VEC; ++v)
+                if (c0 + v < a.cols_pad) a.out[r * a.ldo + c0 + v] = o[v];
+        }
     }
 }
 

@@ -2,6 +2,8 @@
 // reference agent.py:66-82 adds the picked sites and the mobile readings of a step, agent.py:210 refits from scratch).
 //
 //   X[:, c0:c1) = ( B[:, c0:c1) - X[:, 0:c0) L[c0:c1, 0:c0)^T ) inv(L[c0:c1, c0:c1))^T          c1 - c0 <= 64
+//   (c0 = the train set's old size, c1 = its new size: exactly the appended rows, no alignment -- round 5; rounds 3-4 started
+//   at the 16-column boundary below c0 and ended at the one above c1: 48 columns of MFMA work for 30 new rows)
 //
 // The blocked solve of potrf.hip works in 128-column tiles: after an append of ~32 rows it re-solves the whole open tail
 // block -- one or two 128-wide output tiles whose products walk ALL of V^T (K = N: 40 GB at N = 50 000 x 100 000
@@ -139,22 +141,27 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
         st = (st + 1 == NST) ? 0 : st + 1;
     }
     const int nkt = (int)(g.c0 / BK);
-    const int ktail = (int)(g.c0 - (int64_t)nkt * BK);             // fp32 only: 16 elements left over (half a k-tile)
+    const int ktail = (int)(g.c0 - (int64_t)nkt * BK);             // columns behind the last full k-tile: c0 need not be aligned
     if (with_ktail && ktail > 0) {
-        // fp32, c0 = 16 (mod 32): the last 16 columns as plain fragment loads (64 bytes per row: chunk fg of the row)
-        __syncthreads();
+        // the first new column is the train set's old size, any number: the columns [nkt BK, c0) as plain masked loads, four
+        // per MFMA step (lane group fg supplies k = k0 + 4 s + fg); columns from c0 on are the ones being computed: zero
         const int64_t k0 = (int64_t)nkt * BK;
+        for (int s4 = 0; 4 * s4 < ktail; ++s4) {
+            const int64_t kk = k0 + 4 * s4 + fg;
+            const bool in = kk < g.c0;
+            T b[2], a[NT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const chunk_t b = *reinterpret_cast<const chunk_t*>(g.X + (m0 + 32 * wave + 16 * j + fr) * g.ldx + k0 + fg * EPC);
+            for (int j = 0; j < 2; ++j) b[j] = in ? g.X[(m0 + 32 * wave + 16 * j + fr) * g.ldx + kk] : (T)0;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 int row = 16 * i + fr;
                 if (row >= g.lrows_valid) row = g.lrows_valid - 1;
-                const chunk_t a = *reinterpret_cast<const chunk_t*>(g.Lrows + (int64_t)row * g.ldl + k0 + fg * EPC);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[i][j] = F::mfma(a[e], b[e], acc[i][j]);
+                a[i] = in ? g.Lrows[(int64_t)row * g.ldl + kk] : (T)0;
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a[i], b[j], acc[i][j]);
         }
     }
 }
@@ -308,9 +315,9 @@ int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
                      int64_t c0, int w, const T* E_window) {
     if (mpad <= 0 || w <= 0) return ALGP_OK;
     constexpr int G = 16;
-    if (mpad % 128 || c0 % G || w > 64 || (!E_window && c0 / 128 != (c0 + w - 1) / 128) || ldx % 4 || ldl % 4 || lrows < c0 + w)
-        return fail(c, ALGP_ERR_BAD_ARG, "tail_cols: columns must be a 16-aligned range of at most 64 (inside one 128-column block "
-                                         "unless the inverse of the range's own window is supplied)");
+    if (mpad % 128 || w > 64 || (!E_window && (c0 % G || c0 / 128 != (c0 + w - 1) / 128)) || ldx % 4 || ldl % 4 || lrows < c0 + w)
+        return fail(c, ALGP_ERR_BAD_ARG, "tail_cols: at most 64 columns (a 16-aligned range inside one 128-column block unless the "
+                                         "inverse of the range's own window is supplied)");
     TailArgs<T> g;
     g.X = X;
     g.ldx = ldx;
@@ -318,8 +325,9 @@ int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
     g.ldl = ldl;
     g.lrows_valid = (int)std::min<int64_t>(64, lrows - c0);
     const int64_t o = c0 % 128;
-    // E_window: the explicit inverse (ld 128) of the 128 x 128 window of L whose corner is (c0, c0) -- for a range that
-    // straddles two 128-column blocks of the factor, where no stored block inverse covers it
+    // E_window: inv(L[c0 : c0 + w, c0 : c0 + w)) with leading dimension 128 (the caller inverts a 128 x 128 window of L that
+    // contains the range and passes the range's corner of it) -- for a range that starts at an arbitrary column or straddles
+    // two 128-column blocks of the factor, where no stored block inverse covers it
     g.E = E_window ? E_window : invD_blk + o * 128 + o;
     g.c0 = c0;
     g.w = w;

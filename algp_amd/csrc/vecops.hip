@@ -963,21 +963,46 @@ template int set_identity_launch<double>(algp_ctx*, double*, int64_t, int64_t);
 template int set_identity_launch<float>(algp_ctx*, float*, int64_t, int64_t);
 
 // sum_i log L[i][i] for i < n, accumulated into *out (double)
+// acc3[q * stride + rows[e]] = 0 for q < 3: the carried row sums of candidates whose kept columns were zeroed
 template <typename T>
-__global__ __launch_bounds__(256) void logdiag_kernel(const T* L, int64_t ld, int64_t n, double* out) {
-    // one workgroup, fixed summation order: the log-determinant of an updated factor is the same number in every run
-    __shared__ double part[4];
+__global__ void zero_rows3_kernel(T* acc3, int64_t stride, const int64_t* rows, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * n) acc3[(e / n) * stride + rows[e % n]] = (T)0;
+}
+template <typename T>
+int zero_rows3_launch(algp_ctx* c, T* acc3, int64_t stride, const int64_t* rows, int64_t n) {
+    if (n <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(zero_rows3_kernel<T>, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, c->cur, acc3, stride, rows, n);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int zero_rows3_launch<double>(algp_ctx*, double*, int64_t, const int64_t*, int64_t);
+template int zero_rows3_launch<float>(algp_ctx*, float*, int64_t, const int64_t*, int64_t);
+
+// Fixed assignment and fixed summation order: the log-determinant of an updated factor is the same number in every run.
+// Workgroup b takes entries i = 256 (b + G q) + thread; its 4 wave sums go to part[4 b ..]; logdiag_sum_kernel adds the 4 G
+// partials in index order.  (One workgroup walked the 50 000 diagonal entries of config 5's factor -- one cache line each --
+// in 157 us of every planning step; 64 take 12.)
+constexpr int LOGDIAG_G = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void logdiag_kernel(const T* L, int64_t ld, int64_t n, double* part) {
     double v = 0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) v += log((double)L[i * ld + i]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += 256 * LOGDIAG_G) v += log((double)L[i * ld + i]);
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) *out += ((part[0] + part[1]) + (part[2] + part[3]));
+    if ((threadIdx.x & 63) == 0) part[4 * blockIdx.x + (threadIdx.x >> 6)] = v;
+}
+__global__ void logdiag_sum_kernel(const double* part, double* out) {
+    double s = 0;
+    for (int q = 0; q < 4 * LOGDIAG_G; ++q) s += part[q];
+    *out += s;
 }
 template <typename T>
 int logdiag_launch(algp_ctx* c, const T* L, int64_t ld, int64_t n, double* out) {
     if (n <= 0) return ALGP_OK;
-    hipLaunchKernelGGL(logdiag_kernel<T>, dim3(1), dim3(256), 0, c->cur, L, ld, n, out);
+    ALGP_TRY(ensure(c, c->ldpart, sizeof(double) * 4 * LOGDIAG_G));
+    hipLaunchKernelGGL(logdiag_kernel<T>, dim3(LOGDIAG_G), dim3(256), 0, c->cur, L, ld, n, (double*)c->ldpart.p);
+    ALGP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(logdiag_sum_kernel, dim3(1), dim3(1), 0, c->cur, (const double*)c->ldpart.p, out);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

@@ -273,7 +273,7 @@ def extra_c5(_hip, device, picks, steps=200, emu_steps=40):
         pk = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, picks)
         c.sync()
         times.append((time.perf_counter() - t0) * 1e3)
-        crossing.append(bool(s > 0 and kc % 128 == 0 and kc < len(idx) - 64))     # the 128-column blocks were re-solved, not the tail
+        crossing.append(bool(s > 0 and rows[-2] // 128 != (rows[-1] - 1) // 128))  # the new columns straddle a 128-column block of the factor
         if s == 0:
             chol_ms = c.prof_get('cholesky')['ms']
             trsm = c.prof_get('trsm')

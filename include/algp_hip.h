@@ -160,9 +160,9 @@ int algp_set_candidates(algp_ctx* ctx, const int64_t* idx, int64_t M, int prior_
 int algp_solve_candidates(algp_ctx* ctx);
 /* f1: like algp_solve_candidates, but keeps the columns of V^T that were solved against unchanged
  * leading rows of the factor (same candidate list, same hyper-parameters) and solves only the
- * rest: the columns an append added (16-column granularity, up to 64 per 128-column block of the factor;
- * *kept_cols is then a multiple of 16), else the trailing 128-column blocks.  alive[M] (may be NULL)
- * disables candidates that became static-sampled.                                                  */
+ * rest: exactly the columns an append added when there are at most 64 of them (*kept_cols is then the
+ * old train size; one pass over V^T, HBM-bound), else the trailing 128-column blocks.  alive[M] (may
+ * be NULL) disables candidates that became static-sampled.                                         */
 int algp_solve_candidates_update(algp_ctx* ctx, const uint8_t* alive, int64_t* kept_cols);
 /* disable / enable candidates after a solve (alive[M] bytes; 0 = scored as -inf, agent.py:318)      */
 int algp_set_candidate_alive(algp_ctx* ctx, const uint8_t* alive);

@@ -184,8 +184,8 @@ def test_candidate_solve_reuses_columns_and_matches_scratch():
 @pytest.mark.parametrize('dtname', ['f64', 'f32'])
 def test_only_the_new_columns_are_solved_after_an_append(dtname, monkeypatch):
     """After rows were appended behind >= 2 048 unchanged ones, algp_solve_candidates_update solves only the columns the
-    append added (tail.hip: one or two ranges of <= 64 columns, 16-aligned, each inside a 128-column block of the factor)
-    instead of the whole open 128-block.  Appends chosen to hit: one range whose first column is 16 (mod 32) -- the fp32
+    append added (tail.hip: exactly the appended columns when there are at most 64 -- any first column, block boundaries
+    inside the range included) instead of the whole open 128-block.  Appends chosen to hit: one range whose first column is 16 (mod 32) -- the fp32
     kernel's half k-tile --, two ranges across a block boundary with the first 64 wide, an append too wide for it (the
     128-blocks again), a range ending on a block boundary, and a range of <= 64 columns that STRADDLES a block boundary
     (one pass over V^T with the inverse of the window of L at its first column; two passes before round 5).  Every step
@@ -214,7 +214,7 @@ def test_only_the_new_columns_are_solved_after_an_append(dtname, monkeypatch):
         c_.factorize(incremental=True)
         c_.set_candidates(cand, prior_includes_noise=False)
         assert c_.solve_candidates(incremental=True) == 0
-    expect = [(20, 1, 2096), (60, 2, 2112), (70, 0, 2176), (50, 1, 2240), (14, 1, 2288)]      # rows added, tail launches, kept columns
+    expect = [(20, 1, 2100), (60, 1, 2120), (70, 0, 2176), (50, 1, 2250), (14, 1, 2300)]      # rows added, tail launches, kept columns
     for add, launches, kept_want in expect:
         idx = np.arange(len(idx) + add)
         for which, c_ in (('tail', c), ('blocks', b)):
