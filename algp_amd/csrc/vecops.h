@@ -16,6 +16,8 @@ int rows_reduce3_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int
 template <typename T>
 int combine3_launch(algp_ctx* c, int64_t M, const T* acc, const T* tmp, int64_t stride, T ybar, T* ss, T* dot);
 template <typename T>
+int upper_gemv_launch(algp_ctx* c, const T* X, int64_t ld, int64_t n, const T* z, T* out);
+template <typename T>
 int zero_rows3_launch(algp_ctx* c, T* acc3, int64_t stride, const int64_t* rows, int64_t n);
 template <typename T>
 int rowstat_combine_launch(algp_ctx* c, const T* stat, int64_t ld, int ntiles, int64_t rows, T* ss, T* dot);

@@ -963,6 +963,42 @@ template int set_identity_launch<double>(algp_ctx*, double*, int64_t, int64_t);
 template int set_identity_launch<float>(algp_ctx*, float*, int64_t, int64_t);
 
 // sum_i log L[i][i] for i < n, accumulated into *out (double)
+// out[i] = sum_{k >= 128 (i / 128)} X[i][k] z[k] for an upper-triangular X (zero tiles left of the diagonal tile are never read):
+// alpha = L^-T z from the X = L^-T a fit iteration's launch leaves behind.  A workgroup per row, the waves' quarters added in
+// wave order (the same bits in every run).
+template <typename T>
+__global__ __launch_bounds__(256) void upper_gemv_kernel(const T* X, int64_t ld, int64_t n, const T* z, T* out) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ T red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x, k0 = i / 128 * 128;
+    const T* row = X + i * ld;
+    const int64_t nv = (n - k0) / VEC, per = (nv + 3) / 4;
+    const int64_t v0 = wave * per, v1 = v0 + per < nv ? v0 + per : nv;
+    T s = (T)0;
+    for (int64_t v = v0 + lane; v < v1; v += 64) {
+        const vec_t x = *reinterpret_cast<const vec_t*>(row + k0 + v * VEC);
+        const vec_t a = *reinterpret_cast<const vec_t*>(z + k0 + v * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += x[e] * a[e];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+template <typename T>
+int upper_gemv_launch(algp_ctx* c, const T* X, int64_t ld, int64_t n, const T* z, T* out) {
+    if (n <= 0) return ALGP_OK;
+    ProfScope ps(c, ALGP_PROF_TRSV, (double)n * n, sizeof(T) * (double)n * n / 2.0);
+    hipLaunchKernelGGL(upper_gemv_kernel<T>, dim3((unsigned)n), dim3(256), 0, c->cur, X, ld, n, z, out);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int upper_gemv_launch<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, double*);
+template int upper_gemv_launch<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, float*);
+
 // acc3[q * stride + rows[e]] = 0 for q < 3: the carried row sums of candidates whose kept columns were zeroed
 template <typename T>
 __global__ void zero_rows3_kernel(T* acc3, int64_t stride, const int64_t* rows, int64_t n) {

@@ -206,9 +206,12 @@ def test_fit_step_with_the_identity_panel_against_the_three_calls_and_the_oracle
     c.prof_enable(False)
     mll_b, g_b = c.fit_step()
     assert mll == mll_b and np.array_equal(g, g_b)
+    ld = c.logdet()
     c.factorize()
     mll3, g3 = c.mll(), c.mll_grad()
-    assert mll3 == mll                                   # the factor does not depend on the panel
+    assert c.logdet() == ld                              # the factor does not depend on the panel
+    # z = L^-1 (y - ybar) rides along as a row of the panel (tile products) where the three calls substitute: rounding only
+    assert abs(mll3 - mll) <= (1e-12 if dtype == np.float64 else 1e-6) * abs(mll)
     assert np.max(np.abs(g3 - g) / np.maximum(1.0, np.abs(g))) <= (1e-10 if dtype == np.float64 else 2e-3)
     if kernel == _hip.KERNEL_RBF:
         f0, go = O.mll_and_grad(hyp, X, y, var)          # the oracle's are per train point (the reference's loss is -MLL/N)
