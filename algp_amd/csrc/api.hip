@@ -344,8 +344,6 @@ struct Impl {
         bool inv_enqueued = false; // the launch, beside the substitutions and read-backs that follow on the main stream
         int64_t z_row = -1;        // this row of P holds y - ybar (mode 1: a padding row; mode 2: a dense tile row behind the identity):
                                    // z^T = (y - ybar)^T L^-T comes out of the launch too
-        bool syrk_in_launch = false;   // mode 2 with inv_out: S^-1 = X X^T as tasks of the same launch (DAG_SYRK) instead of a launch behind it
-        bool inv_done = false;
     };
     static bool panel_fits(int64_t npad, int64_t mpad) {
         const int64_t nt = npad / NB, mt = mpad / NB;
@@ -359,12 +357,10 @@ struct Impl {
         double* sc = (double*)c->scal.p;
         ALGP_HIP(hipMemsetAsync(sc + slot_logdet, 0, 2 * sizeof(double), c->stream));
         if (panel && panel_fits(npad, panel->mpad)) {
-            const bool fold_syrk = panel->mode == 2 && panel->inv_out && panel->syrk_in_launch;
             ALGP_TRY(cholesky_dag_panel<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info), panel->P, panel->ldp,
-                                           panel->mpad, panel->mode, fold_syrk ? panel->inv_out : (T*)nullptr, npad));
+                                           panel->mpad, panel->mode));
             panel->done = true;
-            panel->inv_done = fold_syrk;
-            if (!fold_syrk && panel->mode == 2 && panel->inv_out && c->stream2 && c->cur == c->stream) {
+            if (panel->mode == 2 && panel->inv_out && c->stream2 && c->cur == c->stream) {
                 hipEvent_t ready = sync_event_api(c, 20), done = sync_event_api(c, 21);
                 ALGP_HIP(hipEventRecord(ready, c->stream));
                 ALGP_HIP(hipStreamWaitEvent(c->stream2, ready, 0));
@@ -1896,7 +1892,7 @@ struct Impl {
 
     // have_X: c->auxW already holds X = L^-T (it rode along with the factorisation as an identity panel); inv_enqueued: and
     // S^-1 = X X^T is already running on the helper stream (event 21 marks its end)
-    static int mll_grad(algp_ctx* c, double* grad_out, bool have_X = false, bool inv_enqueued = false, bool inv_done = false) {
+    static int mll_grad(algp_ctx* c, double* grad_out, bool have_X = false, bool inv_enqueued = false) {
         if (!c->factored || c->train_dirty) return fail(c, ALGP_ERR_STATE, "get_mll_grad: call algp_factorize first");
         if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "get_mll_grad needs a coordinate pool");
         const int64_t N = c->N, Npad = c->Npad;
@@ -1915,8 +1911,7 @@ struct Impl {
             ALGP_TRY(set_identity_launch<T>(c, p(c->auxW), Npad, Npad));
             ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->L), c->Lld, p(c->invD)));
         }
-        if (inv_done) { /* S^-1 came out of the factorisation's own launch */ }
-        else if (inv_enqueued) ALGP_HIP(hipStreamWaitEvent(c->stream, sync_event_api(c, 21), 0));
+        if (inv_enqueued) ALGP_HIP(hipStreamWaitEvent(c->stream, sync_event_api(c, 21), 0));
         else ALGP_TRY(syrk_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->auxW), Npad, Npad, p(c->auxA), Npad));
         double* sc = (double*)c->scal.p + SC_GRAD;        // slots 16..27: os, trace, ls[0..8)
         ALGP_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 12, c->stream));
@@ -1943,14 +1938,13 @@ struct Impl {
     static int fit_step(algp_ctx* c, double* mll_out, double* grad_out) {
         if (c->pool_is_cov) return fail(c, ALGP_ERR_BAD_ARG, "fit_step needs a coordinate pool");
         const int64_t Npad = c->Npad;
-        bool have_X = false, inv_enq = false, inv_done = false;
+        bool have_X = false, inv_enq = false;
         // Round 5: z rides along too (a dense tile row behind the identity that carries y - ybar), and alpha = X z is one pass
         // over the X the launch leaves -- no substitution chain runs beside S^-1 = X X^T any more (the two took 5.5 ms there,
-        // starved by the GEMM).  $ALGP_FIT_ONE_LAUNCH=0: round 4's form.  $ALGP_FIT_SYRK_DAG=1: X X^T as DAG_SYRK tasks of the
-        // same launch as well -- measured: the launch grows by what the separate 5.1-ms GEMM launch costs (12.9 -> 18.9 ms at
-        // N = 10 000 fp64): the list leaves nothing idle to fill, and its tile rate is below the big GEMM's.  Off.
+        // starved by the GEMM).  $ALGP_FIT_ONE_LAUNCH=0: round 4's form.  (X X^T as tasks of the same launch as well was built
+        // and measured in round 5 -- the launch grew by what the separate 5.1-ms GEMM launch costs, 12.9 -> 18.9 ms at N = 10 000
+        // fp64: the list leaves nothing idle to fill -- and removed again: DESIGN.md appendix.)
         static const bool one_launch = !(getenv("ALGP_FIT_ONE_LAUNCH") && atoi(getenv("ALGP_FIT_ONE_LAUNCH")) == 0);
-        static const bool syrk_dag = getenv("ALGP_FIT_SYRK_DAG") && atoi(getenv("ALGP_FIT_SYRK_DAG")) != 0;
         const int64_t prow = (one_launch && grad_out) ? Npad + NB : Npad;
         if (c->N > 0 && panel_fits(Npad, prow)) {
             ALGP_TRY(ensure(c, c->auxW, sizeof(T) * prow * Npad));
@@ -1962,20 +1956,18 @@ struct Impl {
                 ALGP_HIP(hipMemsetAsync(p(c->auxW) + Npad * Npad, 0, sizeof(T) * NB * Npad, c->stream));
                 ALGP_HIP(hipMemcpyAsync(p(c->auxW) + Npad * Npad, c->y0.p, sizeof(T) * Npad, hipMemcpyDeviceToDevice, c->stream));
                 pn.z_row = Npad;
-                pn.syrk_in_launch = syrk_dag;
             }
             const int frc = factorize(c, 0, &pn);
             if (pn.inv_enqueued && (frc != ALGP_OK || !grad_out)) hipStreamSynchronize(c->stream2);   // nothing outlives the call
             ALGP_TRY(frc);
             have_X = pn.done;
             inv_enq = pn.inv_enqueued;
-            inv_done = pn.inv_done;
         } else {
             ALGP_TRY(factorize(c, 0));
         }
         if (mll_out) *mll_out = -0.5 * c->yalpha - 0.5 * c->logdet - 0.5 * (double)c->N * 1.8378770664093453;
         if (!grad_out) return ALGP_OK;
-        const int grc = mll_grad(c, grad_out, have_X, inv_enq, inv_done);
+        const int grc = mll_grad(c, grad_out, have_X, inv_enq);
         if (grc != ALGP_OK && inv_enq) hipStreamSynchronize(c->stream2);
         return grc;
     }

@@ -38,7 +38,7 @@
 
 namespace algp {
 
-enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2, DAG_TU = 3, DAG_SYRK = 4 };
+enum { DAG_CHAIN = 0, DAG_TRSM = 1, DAG_UPD = 2, DAG_TU = 3 };
 #ifndef ALGP_DAG_STRIP_ROWS
 #define ALGP_DAG_STRIP_ROWS 32
 #endif
@@ -57,9 +57,6 @@ struct DagArgs {
     T* invD;
     T* P;                                                      // the row panel below the factor (tile rows nt .. nt+mt-1), or null
     int64_t ldp;
-    T* S;                                                      // DAG_SYRK: the nt x nt tile matrix that receives X X^T (lower tiles), or null
-    int64_t lds;
-    int R;                                                     // nt + mt: the SYRK tiles' versions sit in rows R .. R + nt - 1 of `ver`
     int no_team;                                               // solve-only list: L is final, every workgroup draws tickets
     const DagTask* tasks;
     int ntasks, nt;
@@ -231,23 +228,16 @@ __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, i
     }
 }
 // UPD: tile (i, j) -= L_i,[k0,k1) L_j,[k0,k1)^T.  TRSM (upd == false): tile (i, j) <- tile (i, j) X_jj^T, in place.
-// syrk (with upd): tile (ti, tj) of S += P_ti,[k0,k1) P_tj,[k0,k1)^T for panel rows ti, tj (first: the tile is written, not read).
 template <typename T>
-__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1, bool syrk = false,
-                                            bool first = false) {
+__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     const int lane = threadIdx.x & 63, fr = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     int64_t ldr;
-    T* Ri = dag_row(g, syrk ? g.nt + ti : ti, ldr);            // tile row ti (factor or panel)
+    T* Ri = dag_row(g, ti, ldr);                               // tile row ti (factor or panel)
     T* Cij = Ri + (int64_t)tj * 128;
-    int64_t ldc = ldr;
-    if (syrk) {
-        Cij = g.S + (int64_t)ti * 128 * g.lds + (int64_t)tj * 128;
-        ldc = g.lds;
-    }
     DAG_PHASE(ph0);
     acc_t acc[4][4];
     const T* A0;
@@ -255,25 +245,18 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
     int64_t ldb;
     int nkt;
     if (upd) {
-        // acc = -C, then acc += A B^T, then C = -acc   (syrk: acc = +C or 0, C = acc)
-        const T s0 = syrk ? (T)1 : (T)-1;
+        // acc = -C, then acc += A B^T, then C = -acc
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][r] = first ? (T)0 : s0 * Cij[gi * ldc + wc * 64 + j * 16 + fr];
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = -Cij[gi * ldr + wc * 64 + j * 16 + fr];
             }
         A0 = Ri + (int64_t)k0 * 128;
-        if (syrk) {
-            int64_t ldq;
-            B0 = dag_row(g, g.nt + tj, ldq) + (int64_t)k0 * 128;
-            ldb = ldq;
-        } else {
-            B0 = g.L + (int64_t)tj * 128 * g.ld + (int64_t)k0 * 128;
-            ldb = g.ld;
-        }
+        B0 = g.L + (int64_t)tj * 128 * g.ld + (int64_t)k0 * 128;
+        ldb = g.ld;
         nkt = (k1 - k0) * (128 / (4 * F::EPC));
     } else {
 #pragma unroll
@@ -290,14 +273,14 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
     DAG_PHASE(ph1);
     tile_mainloop<T>(smem, A0, ldr, B0, ldb, nkt, acc);
     DAG_PHASE(ph2);
-    const T sgn = (upd && !syrk) ? (T)-1 : (T)1;
+    const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t gi = wr * 64 + i * 16 + F::row_of(lane, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * ldc + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
+            for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * ldr + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
         }
 #ifdef ALGP_DAG_DEBUG
     // Where a K = 128 product spends its time (tools/dag_test.hip prints the means): "issuing" the 64 loads / 64 stores
@@ -573,15 +556,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         }
         // ---- wait for the inputs: lane l polls dependency l ----
         int ndeps, di = ti, dj = tj, want = 0;
-        if (type == DAG_SYRK) {
-            // S_(ti,tj) += X_ti,[k0,k1) X_tj,[k0,k1)^T: the output tile at version k0 (its earlier batches applied, ascending k),
-            // the panel tiles (nt + ti, kk), (nt + tj, kk) solved
-            const int n = k1 - k0;
-            ndeps = 1 + (ti == tj ? n : 2 * n);
-            if (lane == 0) { di = g.R + ti; want = k0; }
-            else if (lane <= n) { di = nt + ti; dj = k0 + lane - 1; want = dj + 1; }
-            else { di = nt + tj; dj = k0 + lane - n - 1; want = dj + 1; }
-        } else if (type == DAG_TRSM) {
+        if (type == DAG_TRSM) {
             ndeps = 2;
             if (lane == 0) want = tj;                          // tile (i,k) updated k times
             else { di = tj; dj = tj; want = tj + 1; }          // diagonal block k factored
@@ -596,13 +571,13 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         DAG_DBG(1, 2);
         DAG_TRACE(t, 1);
         const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
-        dag_tile_op<T>(g, sm.gemm, type != DAG_TRSM, ti, tj, k0, k1, type == DAG_SYRK, type == DAG_SYRK && k0 == ti);
+        dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1);
         const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - tick0;
-        if (type != DAG_TRSM) { st_upd += ticks; st_steps += (unsigned)(k1 - k0); }
+        if (type == DAG_UPD) { st_upd += ticks; st_steps += (unsigned)(k1 - k0); }
         else { st_trsm += ticks; ++st_ntrsm; }
         DAG_DBG(1, 3);
         DAG_TRACE(t, 2);
-        if (t != g.skip_publish) dag_publish<T>(g, type == DAG_SYRK ? g.R + ti : ti, tj, (type != DAG_TRSM) ? k1 : tj + 1);
+        if (t != g.skip_publish) dag_publish<T>(g, ti, tj, (type == DAG_UPD) ? k1 : tj + 1);
         DAG_DBG(1, 4);
         DAG_TRACE(t, 3);
     }
@@ -649,12 +624,9 @@ struct DagSchedule {
 struct DagShape {
     int nt = 0, mt = 0, mode = 0;
     bool solve_only = false;
-    // mode 2 extras (one iteration of GPR.fit, models.py:145-158): tile rows behind the nt identity rows are dense (the row that
-    // carries y - ybar -> z), and with `syrk` the list also holds the tile products S^-1 = X X^T of the finished rows of
-    // X = L^-T (DAG_SYRK, lowest priority: they fill whatever the factorisation leaves idle)
-    bool syrk = false;
+    // mode 2: tile rows behind the nt identity rows are dense (mt = nt + 1 in algp_fit_step: the row that carries y - ybar -> z)
     int pstart(int e) const { return (mode == 2 && e < nt) ? e : 0; }      // first non-zero tile column of panel row e
-    bool operator==(const DagShape& o) const { return nt == o.nt && mt == o.mt && mode == o.mode && solve_only == o.solve_only && syrk == o.syrk; }
+    bool operator==(const DagShape& o) const { return nt == o.nt && mt == o.mt && mode == o.mode && solve_only == o.solve_only; }
 };
 
 constexpr int DAG_FAR8 = 4, DAG_FAR16 = 16;                    // see the batches in dag_build_schedule
@@ -675,7 +647,7 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
         std::vector<int> succ_start;                                        // nodes that may start once this one HAS STARTED
     };
     std::vector<Node> nodes;
-    std::vector<int> last_writer((size_t)R * nt, -1), trsm((size_t)R * nt, -1), diag(nt, -1), last_syrk(shape.syrk ? (size_t)nt * nt : 0, -1);
+    std::vector<int> last_writer((size_t)R * nt, -1), trsm((size_t)R * nt, -1), diag(nt, -1);
     auto add = [&](int type, int i, int j, int k0, int k1, float dur) {
         Node n;
         n.t = DagTask{type, i, j, (k0 << 16) | k1};
@@ -823,26 +795,6 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
                 if (k0 < j - 1) upd(nt + e, j, k0, j - 1);
             }
         };
-        // S^-1 = X X^T, tile (a, b), a >= b: the sum over the tile columns k >= a of X's rows a and b, in batches that end
-        // where k + 1 is a multiple of 16 (of 4 in the last sixteen columns, so that little is left when the chain ends)
-        if (shape.syrk) {
-            const int tail0 = std::max(0, (nt - 1) / 16 * 16 - 16);
-            const int step = k >= tail0 ? 4 : 16;
-            if ((k + 1) % step == 0 || k + 1 == nt) {
-                const int kb = k / step * step;
-                for (int a = 0; a <= k; ++a)
-                    for (int b = 0; b <= a; ++b) {
-                        const int k0 = std::max(a, kb);
-                        const int u = add(DAG_SYRK, a, b, k0, k + 1, D_OVH + D_OP * (k + 1 - k0));
-                        edge(last_syrk[(size_t)a * nt + b], u);
-                        for (int kk = k0; kk <= k; ++kk) {
-                            edge(trsm[(size_t)(nt + a) * nt + kk], u);
-                            if (b != a) edge(trsm[(size_t)(nt + b) * nt + kk], u);
-                        }
-                        last_syrk[(size_t)a * nt + b] = u;
-                    }
-            }
-        }
         if (k + 2 < nt) panel_near(k + 2);
         for (int j = k + 1; j < nt; ++j) {
             if (mt > 0) panel_far(j);
@@ -991,16 +943,16 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
 // begin at their own column), copied from a template kept beside the task list.
 template <typename T>
 static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* invD, T* P, int64_t ldp, double* logdet_acc,
-                      int* info, T* S = nullptr, int64_t lds = 0) {
+                      int* info) {
     const int nt = shape.nt, mt = shape.mt, R = nt + mt;
     const int W = 2;     // fine (K=128) steps next to a tile's own column; >= 2: the team owns rows k+1, k+2.  With the K = 1024 / 2048
                          // batches of round 3: W = 2 / 3 / 4 / 6 -> 7.28 / 7.32 / 7.28 / 7.53 ms in fp64, 4.49 / 4.58 / 4.86 / 5.10 ms in fp32
-    const size_t nver = (size_t)(R + (shape.syrk ? nt : 0)) * nt;   // the SYRK tiles' versions behind the panel's
+    const size_t nver = (size_t)R * nt;
     const size_t state_bytes = round_up((int64_t)(sizeof(int) * (nver + (DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt) + sizeof(double) * 128 * nt + 16), 16);
     const size_t ver_off = sizeof(double) * 128 * nt + sizeof(int) * ((DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt);
     DagCache* dc = nullptr;
     for (auto& e : c->dag_cache)
-        if (e.nt == nt && e.mt == mt && e.mode == shape.mode + (shape.syrk ? 16 : 0) && e.solve_only == (shape.solve_only ? 1 : 0)) dc = &e;
+        if (e.nt == nt && e.mt == mt && e.mode == shape.mode && e.solve_only == (shape.solve_only ? 1 : 0)) dc = &e;
     if (!dc) {
         hipDeviceProp_t prop;
         ALGP_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -1016,7 +968,7 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
         DagCache e;
         e.nt = nt;
         e.mt = mt;
-        e.mode = shape.mode + (shape.syrk ? 16 : 0);
+        e.mode = shape.mode;
         e.solve_only = shape.solve_only ? 1 : 0;
         e.workers = workers;
         e.ntasks = (int)sched.tasks.size();
@@ -1030,9 +982,6 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
                     for (int j = 0; j <= i; ++j) ver[(size_t)i * nt + j] = j + 1;
             for (int r = 0; r < mt; ++r)                       // a panel row counts its column steps from its first column
                 for (int j = shape.pstart(r); j < nt; ++j) ver[(size_t)(nt + r) * nt + j] = shape.pstart(r);
-            if (shape.syrk)                                    // tile (a, b) of X X^T starts at tile column a
-                for (int a = 0; a < nt; ++a)
-                    for (int b = 0; b <= a; ++b) ver[(size_t)(R + a) * nt + b] = a;
             int rc = ensure(c, e.init, state_bytes);
             if (rc != ALGP_OK) { (void)hipFree(e.tasks.p); c->dev_bytes -= (int64_t)e.tasks.cap; return rc; }
             ALGP_HIP(hipMemcpy(e.init.p, st.data(), state_bytes, hipMemcpyHostToDevice));
@@ -1049,9 +998,6 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
     g.invD = invD;
     g.P = P;
     g.ldp = ldp;
-    g.S = S;
-    g.lds = lds;
-    g.R = R;
     g.no_team = shape.solve_only ? 1 : 0;
     g.tasks = (const DagTask*)dc->tasks.p;
     g.ntasks = dc->ntasks;
@@ -1079,8 +1025,7 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
     const double npad = 128.0 * nt, mrows = 128.0 * mt;
     // flop executed: N^3/3 for the factor, N^2 per dense panel row, N^3/3 in all for the identity panel
     const double flops = (shape.solve_only ? 0.0 : npad * npad * npad / 3.0) +
-                         (shape.mode == 1 ? npad * npad * mrows : (shape.mode == 2 ? npad * npad * npad / 3.0 : 0.0)) +
-                         (shape.syrk ? npad * npad * npad / 3.0 : 0.0);
+                         (shape.mode == 1 ? npad * npad * mrows : (shape.mode == 2 ? npad * npad * npad / 3.0 : 0.0));
     {
         ProfScope ps(c, mt > 0 ? ALGP_PROF_DAG_PANEL : ALGP_PROF_CHOL_DAG, flops, sizeof(T) * npad * (npad + mrows));
         int grid = dc->workers;                                // the machine the list schedule was simulated for
@@ -1109,17 +1054,15 @@ template int cholesky_dag<float>(algp_ctx*, float*, int64_t, int64_t, float*, do
 // (mode 1: dense rows, the candidates' B^T -> V^T; mode 2: P = I, npad x npad -> L^-T, zero tiles never touched).
 template <typename T>
 int cholesky_dag_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info, T* P, int64_t ldp,
-                       int64_t mpad, int mode, T* S, int64_t lds) {
+                       int64_t mpad, int mode) {
     DagShape sh;
     sh.nt = (int)(npad / NB);
     sh.mt = (int)(mpad / NB);
     sh.mode = mode;
-    sh.syrk = mode == 2 && S != nullptr;
-    return dag_launch<T>(c, sh, A, ld, invD, P, ldp, logdet_acc, info, S, lds);
+    return dag_launch<T>(c, sh, A, ld, invD, P, ldp, logdet_acc, info);
 }
-template int cholesky_dag_panel<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*, double*, int64_t, int64_t, int, double*,
-                                        int64_t);
-template int cholesky_dag_panel<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*, float*, int64_t, int64_t, int, float*, int64_t);
+template int cholesky_dag_panel<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*, double*, int64_t, int64_t, int);
+template int cholesky_dag_panel<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*, float*, int64_t, int64_t, int);
 
 // P <- P L^-T against a factor that is final (same task list without the factorisation's own tasks)
 template <typename T>

@@ -365,10 +365,9 @@ bool dag_enabled();       // $ALGP_CHOL_DAG != 0
 // The factorisation and P <- P L^-T in one launch (P: mpad rows riding along as extra block rows of the task list;
 // mode 1: dense rows, mode 2: P = I of the factor's size -> L^-T); and the same solve against a factor that is final.
 template <typename T>
-// (mode 2: the identity's nt tile rows may be followed by dense tile rows -- mpad > npad --, and with S != null the launch also
-// leaves S^-1 = X X^T, lower tiles, in S (leading dimension lds))
+// (mode 2: the identity's nt tile rows may be followed by dense tile rows -- mpad > npad)
 int cholesky_dag_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info, T* P, int64_t ldp,
-                       int64_t mpad, int mode, T* S = nullptr, int64_t lds = 0);
+                       int64_t mpad, int mode);
 template <typename T>
 int solve_dag_panel(algp_ctx* c, const T* L, int64_t npad, int64_t ld, const T* invD, int* info, T* P, int64_t ldp, int64_t mpad,
                     int mode);

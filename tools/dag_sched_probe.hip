@@ -26,12 +26,7 @@ struct Replay {
     int lead_k = 0, help_k = 0, help_phase = 0;
     // the initial versions are what dag_launch's template holds: 0, a final factor for a solve-only list, and for a
     // panel row its first column
-    std::vector<int> sver;                                     // SYRK output tiles (a, b): columns of X X^T applied so far
-    int& sv(int a, int b) { return sver[(size_t)a * nt + b]; }
-    explicit Replay(const DagShape& s) : nt(s.nt), sh(s), ver((size_t)(s.nt + s.mt) * s.nt, 0), sver(s.syrk ? (size_t)s.nt * s.nt : 0, 0) {
-        if (s.syrk)
-            for (int a = 0; a < nt; ++a)
-                for (int b = 0; b <= a; ++b) sv(a, b) = a;
+    explicit Replay(const DagShape& s) : nt(s.nt), sh(s), ver((size_t)(s.nt + s.mt) * s.nt, 0) {
         if (s.solve_only) {
             for (int i = 0; i < nt; ++i)
                 for (int j = 0; j <= i; ++j) v(i, j) = j + 1;
@@ -74,16 +69,6 @@ struct Replay {
             printf("nt %d ticket %d type %d (%d,%d) k %d..%d: %s\n", nt, ticket, t.type, i, j, k0, k1, why);
             return false;
         };
-        if (t.type == DAG_SYRK) {
-            if (!sh.syrk || i >= nt || j > i || k0 < i || k1 > nt || k1 <= k0) return bad("SYRK tile or columns outside X X^T");
-            if (sv(i, j) != k0) return bad("SYRK tile is not at version k0");
-            for (int kk = k0; kk < k1; ++kk) {
-                if (v(nt + i, kk) < kk + 1) return bad("X_a,kk not solved");
-                if (v(nt + j, kk) < kk + 1) return bad("X_b,kk not solved");
-            }
-            sv(i, j) = k1;
-            return true;
-        }
         if (i >= nt + sh.mt || j >= nt) return bad("tile outside the matrix");
         if (i >= nt && (j < sh.pstart(i - nt) || k0 < sh.pstart(i - nt))) return bad("a panel row touched left of its first column");
         if (t.type == DAG_TU) {
@@ -132,13 +117,6 @@ static bool check(const DagShape& sh, int W, int workers) {
                        workers, i, j, r.v(i, j));
                 return false;
             }
-    if (sh.syrk)
-        for (int a = 0; a < nt; ++a)
-            for (int b = 0; b <= a; ++b)
-                if (r.sv(a, b) != nt) {
-                    printf("nt %d: X X^T tile (%d,%d) ends at version %d\n", nt, a, b, r.sv(a, b));
-                    return false;
-                }
     return true;
 }
 
@@ -164,8 +142,10 @@ int main(int argc, char** argv) {
         for (int nt = lo; nt <= hi; ++nt)
             for (int mode : {1, 2})
                 for (int so : {0, 1})
-                    for (int mt : {1, 3, nt, 2 * nt + 5}) {
-                        if (mode == 2 && mt != nt) continue;
+                    for (int mt : {1, 3, nt, nt + 1, 2 * nt + 5}) {
+                        // mode 2: the identity alone, or followed by one dense tile row (the row that carries y - ybar: algp_fit_step)
+                        if (mode == 2 && mt != nt && mt != nt + 1) continue;
+                        if (mode == 1 && mt == nt + 1) continue;
                         for (int workers : {512, 37, 2 * DAG_TEAM + 1}) {
                             DagShape sh;
                             sh.nt = nt; sh.mt = mt; sh.mode = mode; sh.solve_only = so != 0;
@@ -173,16 +153,6 @@ int main(int argc, char** argv) {
                             ++n;
                         }
                     }
-        // one iteration of GPR.fit as algp_fit_step sends it: the identity + one dense tile row (y - ybar -> z) + the X X^T products
-        int nfit = 0;
-        for (int nt = lo; nt <= hi; ++nt)
-            for (int workers : {512, 37, 2 * DAG_TEAM + 1}) {
-                DagShape sh;
-                sh.nt = nt; sh.mt = nt + 1; sh.mode = 2; sh.syrk = true;
-                if (!check(sh, W, workers)) return 1;
-                ++nfit;
-            }
-        printf("CHECK OK: %d fit-iteration schedules (identity + dense row + X X^T)\n", nfit);
         printf("CHECK OK: %d panel schedules (N/128 = %d..%d)\n", n, lo, hi);
         return 0;
     }
@@ -190,7 +160,6 @@ int main(int argc, char** argv) {
         // one shape, e.g. the largest the library sends: --check-shape NT MT MODE SOLVE_ONLY
         DagShape sh;
         sh.nt = atoi(argv[2]); sh.mt = atoi(argv[3]); sh.mode = atoi(argv[4]); sh.solve_only = atoi(argv[5]) != 0;
-        sh.syrk = argc > 6 && atoi(argv[6]) != 0;              // mode 2 only: the list also holds the X X^T products
         for (int workers : {512, 2 * DAG_TEAM + 1})
             if (!check(sh, 2, workers)) return 1;
         printf("CHECK OK: shape nt %d mt %d mode %d solve_only %d\n", sh.nt, sh.mt, sh.mode, (int)sh.solve_only);
