@@ -231,6 +231,23 @@ def _pct(v, q):
     return float(np.percentile(np.asarray(v, dtype=np.float64), q))
 
 
+def _tail_traffic(alg_bytes):
+    """HBM-side bytes per launch of the tail kernel from the PMC passes in profiles/ (2 x FETCH_SIZE + WRITE_SIZE, own --pmc
+    passes of tools/collect_c5_profiles.sh), scaled from the sizes they were taken at to this run's: measured / algorithmic
+    there x algorithmic here.  None when the file or the kernel's sources (tail.hip) changed since."""
+    import hashlib
+    try:
+        tj = json.load(open(os.path.join(REPO, 'profiles', 'r05_traffic_pmc.json')))
+        sha = hashlib.sha256(open(os.path.join(REPO, 'algp_amd', 'csrc', 'tail.hip'), 'rb').read()).hexdigest()[:16]
+        if tj.get('tail_sources_sha16') != sha:
+            return None, {'note': 'null: tail.hip changed since the PMC passes', 'tail_sources_sha16_now': sha,
+                          'tail_sources_sha16_measured': tj.get('tail_sources_sha16')}
+        ratio = tj['tail_part_f64_bytes_per_launch'] / tj['tail_part_f64_algorithmic_bytes_per_launch_same_run']
+        return ratio * alg_bytes, {'source': 'profiles/r05_traffic_pmc.json', 'measured_over_algorithmic': ratio, 'tail_sources_sha16': sha}
+    except Exception as e:
+        return None, {'note': 'null: %s' % e}
+
+
 def extra_c5(_hip, device, picks, steps=200, emu_steps=40):
     """BASELINE config 5: 50 000-point field fp64, 100 000 candidates, the active-learning loop (reference agent.py:125-229:
     greedy :141 -> _add_samples :66-82 -> refit :196-210) -- on ONE GPU: one from-scratch planning step, then `steps`
@@ -297,6 +314,7 @@ def extra_c5(_hip, device, picks, steps=200, emu_steps=40):
     unprof, prof = inc[:prof_from - 1], inc[prof_from - 1:]
     cross = np.array(crossing[1:])
     tail_gbs = tail['bytes'] / (tail['ms'] * 1e-3) / 1e9 if tail['ms'] > 0 else None
+    tail_traffic, tail_traffic_info = _tail_traffic(tail['bytes'] / max(1, tail['launches']))
     out = {'workload': 'C5 on one GPU: 50 000-point field, fp64, 100 000 candidates, %d picks + 26 mobile readings per step, %d '
                        'incremental steps after one from-scratch step' % (picks, steps), 'dtype': 'f64',
            'from_scratch_step_ms': times[0], 'incremental_steps': int(steps), 'loop_total_s': loop_s,
@@ -309,9 +327,10 @@ def extra_c5(_hip, device, picks, steps=200, emu_steps=40):
            'step_ms_first_20': [round(t, 2) for t in times[:21]],
            'train_rows_first_last': [rows[0], rows[-1]],
            'fit_ms': chol_ms, 'cholesky_tflops': ctf, 'device_gb': dev_gb,
-           'incremental_roofline': {'bound': 'hbm', 'kernel': 'tail_cols_kernel<double> (the new columns of V^T after an append)',
+           'incremental_roofline': {'bound': 'hbm', 'kernel': 'tail_part_kernel<double> + tail_finish_kernel<double> (tail.hip: the new columns of V^T after an append; one launch pair)',
                                     'achieved': tail_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                     'frac': tail_gbs / HBM_PEAK_GBS if tail_gbs else None,
+                                    'traffic': tail_traffic, 'traffic_provenance': tail_traffic_info,
                                     'launches': tail['launches'], 'avg_launch_ms': tail['ms'] / max(1, tail['launches']),
                                     'algorithmic_bytes_per_launch': tail['bytes'] / max(1, tail['launches']),
                                     'gemm_launches_in_block_crossing_steps': gt['launches'],
@@ -871,7 +890,7 @@ def main():
                     'instead of the config-4 step (candidates sharded, factor replicated; see loop_mode)')
     ap.add_argument('--loop-field', type=lambda v: tuple(int(x) for x in v.split('x')), default=(250, 200), help='RxC of the loop\'s field (default 250x200 = 50 000 sites)')
     ap.add_argument('--cpu-train', type=int, default=6000)
-    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r04_traffic_pmc.json'))
+    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r05_traffic_pmc.json'))
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -10,7 +10,7 @@ DT=${1:-f64}
 OUT=${2:-gpurun_out/prof_r05_$DT}
 TRAFFIC=${3:-$OUT/traffic_pmc.json}
 ARGS="bench.py --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-emulation --traffic-json $TRAFFIC"
-mkdir -p $OUT
+mkdir -p $OUT $(dirname $TRAFFIC)
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
 python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 echo "plain done"
