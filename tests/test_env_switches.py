@@ -90,3 +90,72 @@ def test_switch_reproduces_default(default_run, switch, exact):
     for name in ('util', 'util2', 'mu', 'pv'):
         for a, b in zip(got[name], ref[name]):
             assert abs(a - b) <= (0.0 if exact else 1e-9 * max(1.0, abs(b))), (switch, name, a, b)
+
+
+# ---- round 5's switches: the tail kernel's forms and z as a row of the panel -----------------------------------------------
+_STEP5 = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from algp_amd import _hip
+rng = np.random.RandomState(8)
+N, M = 2300, 4300                                  # >= 2 048 unchanged rows and >= 2 048 candidate rows: the tail kernel is eligible
+X = rng.uniform(0, 60, size=(N + M + 100, 2))
+y = np.sin(X[:, 0] / 5) + 0.1 * rng.standard_normal(len(X))
+var = np.where(rng.uniform(size=len(X)) < 0.5, 0.01, 1.0)
+cand = np.arange(N + 100, N + 100 + M)
+c = _hip.Context(np.float64)
+c.set_hypers(np.log([3.0, 2.0]), 0.1, np.log(1e-2))
+c.set_pool(X)
+out = {}
+idx = np.arange(N - 40)
+for tag, add in (('a', 0), ('b', 23), ('c', 30)):   # 2260 -> 2283 (unaligned start) -> 2313 (straddles column 2304)
+    idx = np.arange(len(idx) + add)
+    c.set_train(idx, y[idx], var[idx])
+    c.factorize(incremental=True)
+    c.set_candidates(cand, prior_includes_noise=False)
+    kept = c.solve_candidates(incremental=True)
+    mu, pv = c.posterior()
+    out[tag] = {'kept': int(kept), 'mu': [float(v) for v in mu[::67]], 'pv': [float(v) for v in pv[::67]], 'ld': c.logdet()}
+# fit + solve in one launch with padding rows in the candidates' last tile (z rides in one of them), and a fit iteration
+c.set_train(np.arange(N), y[:N], var[:N])
+c.set_candidates(cand[:4001], prior_includes_noise=True)
+c.fit_and_solve()
+mu, pv = c.posterior()
+mll, g = c.fit_step()
+out['fold'] = {'mu': [float(v) for v in mu[::61]], 'pv': [float(v) for v in pv[::61]], 'mll': mll, 'grad': [float(v) for v in g],
+               'alpha': [float(v) for v in c.alpha()[::97]]}
+print(json.dumps(out))
+""" % REPO
+
+
+def _run5(env_extra):
+    env = dict(os.environ)
+    for k in ('ALGP_TAIL_EXACT', 'ALGP_TAIL_STRADDLE', 'ALGP_TAIL_SPLIT', 'ALGP_TAIL_COLS', 'ALGP_Z_IN_PANEL', 'ALGP_FIT_ONE_LAUNCH'):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, '-c', _STEP5], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.fixture(scope='module')
+def default_run5():
+    return _run5({})
+
+
+@pytest.mark.parametrize('switch', ['ALGP_TAIL_EXACT=0', 'ALGP_TAIL_EXACT=0 ALGP_TAIL_STRADDLE=0', 'ALGP_TAIL_SPLIT=0', 'ALGP_TAIL_COLS=0',
+                                    'ALGP_Z_IN_PANEL=0', 'ALGP_FIT_ONE_LAUNCH=0'])
+def test_round5_switch_reproduces_default(default_run5, switch):
+    """Every form the tail kernel replaced (16-aligned columns, a pass per 128-column block, one workgroup per 128 rows, the
+    128-column blocks) and z by a substitution launch instead of a row of the panel: the same posterior, log-determinant,
+    MLL and gradient to rounding.  (Reference: agent.py:210 refits from scratch at every step; models.py:145-158.)"""
+    got, ref = _run5(dict(kv.split('=') for kv in switch.split())), default_run5
+    assert ref['b']['kept'] == 2260 and ref['c']['kept'] == 2283                      # exactly the appended columns by default
+    for tag in ('a', 'b', 'c'):
+        assert abs(got[tag]['ld'] - ref[tag]['ld']) <= 1e-10 * abs(ref[tag]['ld'])
+        for name in ('mu', 'pv'):
+            assert max(abs(a - b) for a, b in zip(got[tag][name], ref[tag][name])) <= 1e-9, (switch, tag, name)
+    for name in ('mu', 'pv', 'grad', 'alpha'):
+        assert max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(got['fold'][name], ref['fold'][name])) <= 1e-9, (switch, name)
+    assert abs(got['fold']['mll'] - ref['fold']['mll']) <= 1e-11 * abs(ref['fold']['mll'])

@@ -185,7 +185,9 @@ def test_c4_one_rank_of_two_is_one_launch_at_the_task_lists_upper_end():
     c.factorize()
     c.solve_candidates()
     mu2, pv2 = c.posterior()
-    assert np.array_equal(mu2, mu) and np.array_equal(pv2, pv)
+    # the same tile arithmetic for V^T either way; z = L^-1 (y - ybar) rides along as a row of the panel in the one launch
+    # (tile products) where the two-call form substitutes: the mean agrees to rounding
+    assert np.array_equal(pv2, pv) and np.max(np.abs(mu2 - mu)) < 1e-12
     c.close()
 
 

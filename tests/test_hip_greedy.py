@@ -184,9 +184,13 @@ def test_fit_and_solve_equals_separate_calls(dtname):
         c.fit_and_solve()
         mu1, d1 = c.posterior()
         s1 = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
-        assert np.array_equal(mu0, mu1) and np.array_equal(d0, d1) and np.array_equal(s0, s1)
+        # V^T, variance, utilities and the factor: the same bits; the mean and alpha go through z, which rides along as a row
+        # of the candidates' panel in the one launch (tile products) where the two calls substitute: rounding
+        rt = 1e-12 if dtname == 'f64' else 2e-5
+        assert np.array_equal(d0, d1) and np.array_equal(s0, s1)
+        assert np.max(np.abs(mu0 - mu1)) <= rt * max(1.0, np.max(np.abs(mu0)))
         assert not np.any(np.isnan(s1))
-        assert c.logdet() == ld0 and np.array_equal(c.alpha(), a0)
+        assert c.logdet() == ld0 and np.max(np.abs(c.alpha() - a0)) <= rt * max(1.0, np.max(np.abs(a0)))
     picks = c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)
     c.factorize()
     c.solve_candidates()
