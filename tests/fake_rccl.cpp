@@ -24,7 +24,7 @@ struct FakeComm;
 typedef FakeComm* ncclComm_t;
 
 constexpr int MAX_RANKS = 16;
-constexpr size_t SLOT = 1 << 20;
+constexpr size_t SLOT = 4 << 20;                               // per rank: a pick's payload, or a factor update's rows (cap rows of the kept width)
 struct Shared {
     int count, gen, calls;
     char pad[52];

@@ -148,3 +148,112 @@ def test_ranks_over_the_rccl_transport(tmp_path, fake_rccl, world, dtname, rows)
         assert 'RCCL_TRANSPORT_OK rank %d' % r in so
     if world == 2:
         assert 'owners [0, 1]' in outs[0][0], outs[0][0]       # winners from both shards: both ranks commit remotely
+
+
+LOOP_WORKER = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %(repo)r)
+from algp_amd import _hip
+from algp_amd.sharded import ShardLink
+assert 'torch' not in sys.modules
+rank, world, tmp = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+
+def exchange(tag, payload=None):
+    path = os.path.join(tmp, tag)
+    if rank == 0:
+        with open(path + '.tmp', 'wb') as f:
+            f.write(payload)
+        os.rename(path + '.tmp', path)
+        return payload
+    t0 = time.time()
+    while not os.path.exists(path):
+        assert time.time() - t0 < 120, 'rank 0 never published ' + tag
+        time.sleep(0.01)
+    return open(path, 'rb').read()
+
+rng = np.random.RandomState(31)
+N0, NC = 2300, 5000
+n = N0 + NC
+X = rng.uniform(0, 55, (n, 2))
+is_static = rng.uniform(size=N0) < 0.5
+
+def make():
+    c = _hip.Context(np.float64)
+    c.set_hypers(np.log([3.0, 2.5]), 0.0, np.log(1e-2))
+    c.set_pool(X)
+    return c
+
+uid = exchange('uid', _hip.Context.comm_unique_id() if rank == 0 else None)
+link = ShardLink(rank, world, unique_id=uid, layout=sys.argv[4])
+mine = link.mine(n)
+ref, sh = make(), make()
+link.attach(sh, n)                                   # algp_comm_init over the double + the owner map
+rows_site, rows_static = list(range(N0)), list(is_static)
+static = np.zeros(n, bool); static[:N0] = is_static
+mobile = np.zeros(n, bool); mobile[:N0] = ~is_static
+y_rows = list(rng.uniform(0, 1, N0))
+r2 = np.random.RandomState(6)
+peers = 0
+for step in range(7):
+    A = np.array(rows_site, dtype=np.int64)
+    var = np.where(np.array(rows_static), 0.01, 1.0)
+    y = np.array(y_rows)
+    res = []
+    for c, cand in ((ref, np.arange(n)), (sh, mine)):
+        c.set_train(A, y, var)
+        c.factorize(incremental=True)               # sharded: agreement word + ONE ncclAllGather of the new rows
+        c.set_candidates(cand, prior_includes_noise=True)
+        c.solve_candidates(incremental=True, alive=~static[cand])
+        mu, pv = c.posterior()
+        res.append((mu, pv, c.logdet()))
+    if step > 0:
+        assert sh.counter(3) == step and sh.counter(4) == 0, (sh.counter(3), sh.counter(4))
+        peers += sh.counter(2)
+    (mu1, pv1, ld1), (mu2, pv2, ld2) = res
+    assert abs(ld1 - ld2) < 1e-9 * abs(ld1) and np.max(np.abs(mu1[mine] - mu2)) < 1e-9 and np.max(np.abs(pv1[mine] - pv2)) < 1e-9, step
+    want = [int(p) for p in ref.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 4)]
+    got = [int(p) for p in sh.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 4)]
+    assert got == want, (step, got, want)
+    path = [int(q) for q in r2.permutation(n)[:12]]
+    for q, st in [(q, True) for q in got] + [(q, False) for q in path if not mobile[q] and q not in got]:
+        rows_site.append(q); rows_static.append(st); y_rows.append(float(r2.uniform(0, 1)))
+        (static if st else mobile)[q] = True
+assert peers > 0
+# an error in one rank's agreement word: every rank returns it, nobody enters the row gather
+A = np.array(rows_site, dtype=np.int64); var = np.where(np.array(rows_static), 0.01, 1.0); y = np.array(y_rows)
+sh.set_train(A, y, var)
+if rank == world - 1:
+    sh.debug_fail_at(3, _hip.ERR_OOM)
+try:
+    sh.factorize(incremental=True)
+    raise SystemExit('rank %%d: the injected failure was lost' %% rank)
+except MemoryError:
+    pass
+sh.comm_destroy(); sh.close(); ref.close()
+print('RCCL_LOOP_OK rank %%d peers %%d' %% (rank, peers))
+'''
+
+
+@pytest.mark.parametrize('world,layout', [(2, 'strided'), (3, 'contiguous')])
+def test_sharded_loop_over_the_rccl_transport(tmp_path, fake_rccl, world, layout):
+    """Config 5's loop on sharded candidates through the RCCL code path of the row exchange (comm.hip: comm_agree's device
+    all-gather + read-back, comm_rows_gather's ncclAllGather of the rows): 2 and 3 ranks on one card against the test double,
+    seven steps each -- picks, posterior and log-determinant of the one-rank loop at every step, every factor update through
+    the exchange, an injected failure returned by every rank (reference agent.py:125-229 with :313-354 sharded)."""
+    script = tmp_path / 'worker.py'
+    script.write_text(LOOP_WORKER % {'repo': REPO})
+    env = dict(os.environ, ALGP_RCCL_PATH=fake_rccl)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(tmp_path), layout], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank %d:\n%s\n%s' % (r, so[-2000:], se[-4000:])
+        assert 'RCCL_LOOP_OK rank %d' % r in so
