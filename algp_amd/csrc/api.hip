@@ -573,7 +573,9 @@ struct Impl {
             ALGP_TRY(gather_rows_launch<T>(c, p(c->Vt), c->ldv, d_src, own, Nb, cap, Nb, second ? d_lrow : nullptr,
                                            second ? (const T*)c->auxVar.p : nullptr, p(c->L), ld));
             ALGP_TRY(sync(c));                                               // src_row / lrow / lscale are host temporaries
-            ALGP_TRY(comm_rows_gather(c, bytes));
+            std::vector<size_t> used((size_t)nr);
+            for (int r = 0; r < nr; ++r) used[(size_t)r] = rowbytes * (size_t)cnt[(size_t)r];
+            ALGP_TRY(comm_rows_gather(c, bytes, used.data()));
             // scatter: factor row p0 + i <- the slot of its owner's contribution; padding rows are zero
             std::vector<int64_t> from((size_t)ntot, -1);
             int64_t peers = 0;

@@ -369,8 +369,11 @@ int comm_rows_reserve(algp_ctx* c, size_t bytes_per_rank) {
     }
     return ALGP_OK;
 }
-// rowx[0 : bytes) of every rank -> rowx[bytes : bytes * (nranks + 1)) in rank order, stream-ordered on c->stream
-int comm_rows_gather(algp_ctx* c, size_t bytes_per_rank) {
+// rowx[0 : bytes) of every rank -> rowx[bytes : bytes * (nranks + 1)) in rank order, stream-ordered on c->stream.
+// used_bytes[r] (or null): how much of rank r's slice carries rows -- the host transport stages only that much up to the
+// device (the plan gives every rank `cap` rows, a rank that owns fewer sends padding) and takes this rank's own slice from
+// the device copy it already holds.
+int comm_rows_gather(algp_ctx* c, size_t bytes_per_rank, const size_t* used_bytes) {
     const int nr = c->comm_nranks;
     char* own = (char*)c->rowx.p;
     char* all = own + bytes_per_rank;
@@ -390,7 +393,16 @@ int comm_rows_gather(algp_ctx* c, size_t bytes_per_rank) {
     c->n_syncs++;
     const int rc = c->host_gather(c->host_gather_user, hs, hr, (int64_t)bytes_per_rank);
     if (rc != 0) return fail(c, ALGP_ERR_HIP, "factorize_update: the caller's all-gather returned " + std::to_string(rc));
-    ALGP_HIP(hipMemcpyAsync(all, hr, bytes_per_rank * (size_t)nr, hipMemcpyHostToDevice, c->stream));
+    if (!used_bytes) {
+        ALGP_HIP(hipMemcpyAsync(all, hr, bytes_per_rank * (size_t)nr, hipMemcpyHostToDevice, c->stream));
+        return ALGP_OK;
+    }
+    for (int r = 0; r < nr; ++r) {
+        const size_t ub = std::min(used_bytes[r], bytes_per_rank);
+        if (ub == 0) continue;
+        if (r == c->comm_rank) ALGP_HIP(hipMemcpyAsync(all + bytes_per_rank * (size_t)r, own, ub, hipMemcpyDeviceToDevice, c->stream));
+        else ALGP_HIP(hipMemcpyAsync(all + bytes_per_rank * (size_t)r, hr + bytes_per_rank * (size_t)r, ub, hipMemcpyHostToDevice, c->stream));
+    }
     return ALGP_OK;
 }
 

@@ -350,7 +350,7 @@ int comm_pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_de
 int comm_reserve(algp_ctx* c);
 int comm_agree(algp_ctx* c, const double mine[4], std::vector<double>& all);
 int comm_rows_reserve(algp_ctx* c, size_t bytes_per_rank);
-int comm_rows_gather(algp_ctx* c, size_t bytes_per_rank);
+int comm_rows_gather(algp_ctx* c, size_t bytes_per_rank, const size_t* used_bytes = nullptr);
 size_t comm_payload_bytes(const algp_ctx* c);
 int comm_debug_first_max(algp_ctx* c, const double* triples, int nranks, double* out5);
 void dag_release(algp_ctx* c);   // frees the cached task lists of the dependency-driven Cholesky
