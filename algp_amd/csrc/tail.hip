@@ -42,19 +42,22 @@ struct TailArgs {
     T* part;
 };
 
-constexpr int TAIL_NST = 3, TAIL_STB = 24576;
+constexpr int TAIL_NST = 3;
+constexpr int tail_stb(int JT) { return 8192 + 8192 * JT; }      // a stage: 64 rows of L + 64 JT rows of V^T, 128 bytes each
 
 // acc += L[c0 .. c0 + 64, k-tiles [kt0, kt1)] (x) X[m0 .. m0 + 128, the same k-tiles]^T for the workgroup's 128 candidate rows;
 // with_ktail: the fp32 half tile behind the last full one as well.  Every wave of the workgroup calls it with the same range.
 // NT: the 16-row tiles of L that carry new columns (ceil(w / 16)), a compile-time constant: the products of a k-tile are one
 // straight run of MFMAs in which consecutive instructions never share an accumulator.
-template <typename T, int NT>
+// JT: 16-candidate tiles per wave -- the workgroup owns 64 JT candidate rows (JT = 2: 72 KB of LDS, two workgroups per CU;
+// JT = 1: 48 KB, three).
+template <typename T, int NT, int JT>
 __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0, int kt0, int kt1, bool with_ktail,
                                                 typename MF<T>::acc_t (&acc)[4][2], char* smem) {
     // k-tiles of 128 bytes per row (the GEMM's are 64): this kernel lives on HBM bandwidth, and with 64-byte pieces of
     // 128 x 512 different rows in flight it reached 2.7 TB/s (14.6 ms for the 40 GB of config 5) -- every piece opens a
     // DRAM page of its own.  Three stages of 24 KB (8 KB of L rows + 16 KB of V^T rows), two k-tiles in flight.
-    constexpr int NST = TAIL_NST, STB = TAIL_STB;
+    constexpr int NST = TAIL_NST, STB = tail_stb(JT);
     using F = MF<T>;
     using chunk_t = typename F::chunk_t;
     constexpr int EPC = F::EPC;
@@ -74,25 +77,25 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
         lr[i] = row < g.lrows_valid ? row : g.lrows_valid - 1;     // never read beyond the factor's rows; such rows are masked below
         Lg[i] = g.Lrows + (int64_t)lr[i] * g.ldl + (slot ^ ((row >> 1) & 7)) * EPC;
     }
-    const T* Xg[4];
+    const T* Xg[2 * JT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 32 * wave + 8 * i + r8;                    // row of the 128-row V^T part
+    for (int i = 0; i < 2 * JT; ++i) {
+        const int row = 16 * JT * wave + 8 * i + r8;               // row of the workgroup's V^T part
         Xg[i] = g.X + (m0 + row) * g.ldx + (slot ^ ((row >> 1) & 7)) * EPC;
     }
     auto stage = [&](int st, int kt) {
         char* As = smem + st * STB + wave * 2048;
-        char* Bs = smem + st * STB + 8192 + wave * 4096;
+        char* Bs = smem + st * STB + 8192 + wave * (2048 * JT);
 #pragma unroll
         for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_vp)(Lg[i] + (int64_t)kt * BK), (lds_vp)(As + i * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_vp)(Xg[i] + (int64_t)kt * BK), (lds_vp)(Bs + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 2 * JT; ++i) __builtin_amdgcn_global_load_lds((glb_vp)(Xg[i] + (int64_t)kt * BK), (lds_vp)(Bs + i * 1024), 16, 0, 0);
     };
     const int fr = lane & 15, fg = lane >> 4;
     // chunk 4 h + fg of row (16 t + fr): slot = (4 h + fg) ^ ((row >> 1) & 7), and (row >> 1) & 7 = (fr >> 1) for every tile
     const int sw = (fr >> 1) & 7;
     const int aoff0 = fr * 128 + ((fg ^ sw) << 4), aoff1 = fr * 128 + (((4 + fg) ^ sw) << 4);
-    const int boff0 = 8192 + (32 * wave + fr) * 128 + ((fg ^ sw) << 4), boff1 = 8192 + (32 * wave + fr) * 128 + (((4 + fg) ^ sw) << 4);
+    const int boff0 = 8192 + (16 * JT * wave + fr) * 128 + ((fg ^ sw) << 4), boff1 = 8192 + (16 * JT * wave + fr) * 128 + (((4 + fg) ^ sw) << 4);
 
     // ALL three stages are in flight: a stage is refilled as soon as every wave holds its fragments in registers (the
     // second barrier), not one iteration later behind the slowest wave's MFMAs.  With two k-tiles in flight and the
@@ -104,20 +107,21 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
     int st = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         const int ahead = kt1 - 1 - kt;                             // k-tiles behind this one that have been issued: min(2, ahead)
-        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F7C);         // vmcnt(12): this tile landed, two may fly (6 DMA per tile)
-        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F76);    // vmcnt(6)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        // this tile landed, two may fly: 2 + 2 JT DMA instructions per tile and wave
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(JT == 2 ? 0x0F7C : 0x0F78);         // vmcnt(12 | 8)
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(JT == 2 ? 0x0F76 : 0x0F74);    // vmcnt(6 | 4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* base = smem + st * STB;
-        chunk_t a0[NT], a1[NT], b0[2], b1[2];
+        chunk_t a0[NT], a1[NT], b0[JT], b1[JT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             a0[i] = *reinterpret_cast<const chunk_t*>(base + aoff0 + i * 2048);
             a1[i] = *reinterpret_cast<const chunk_t*>(base + aoff1 + i * 2048);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JT; ++j) {
             b0[j] = *reinterpret_cast<const chunk_t*>(base + boff0 + j * 2048);
             b1[j] = *reinterpret_cast<const chunk_t*>(base + boff1 + j * 2048);
         }
@@ -130,11 +134,11 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < JT; ++j)
 #pragma unroll
                 for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a0[i][e], b0[j][e], acc[i][j]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < JT; ++j)
 #pragma unroll
                 for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a1[i][e], b1[j][e], acc[i][j]);
         }
@@ -149,9 +153,9 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
         for (int s4 = 0; 4 * s4 < ktail; ++s4) {
             const int64_t kk = k0 + 4 * s4 + fg;
             const bool in = kk < g.c0;
-            T b[2], a[NT];
+            T b[JT], a[NT];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = in ? g.X[(m0 + 32 * wave + 16 * j + fr) * g.ldx + kk] : (T)0;
+            for (int j = 0; j < JT; ++j) b[j] = in ? g.X[(m0 + 16 * JT * wave + 16 * j + fr) * g.ldx + kk] : (T)0;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 int row = 16 * i + fr;
@@ -159,7 +163,7 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
                 a[i] = in ? g.Lrows[(int64_t)row * g.ldl + kk] : (T)0;
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < JT; ++j)
 #pragma unroll
                 for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a[i], b[j], acc[i][j]);
         }
@@ -167,7 +171,7 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
 }
 
 // acc holds the full product for the workgroup's 128 candidates: X_new = (B - acc) inv(D)^T into the w new columns
-template <typename T>
+template <typename T, int JT>
 __device__ __forceinline__ void tail_epilogue(const TailArgs<T>& g, int64_t m0, typename MF<T>::acc_t (&acc)[4][2]) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
@@ -176,11 +180,11 @@ __device__ __forceinline__ void tail_epilogue(const TailArgs<T>& g, int64_t m0, 
     const int fr = lane & 15;
     // T = B - acc for the w new columns (element (new column 16 i + row_of, candidate 32 wave + 16 j + fr)); zero beyond w
     const int w = g.w;
-    T* Xw = g.X + (m0 + 32 * wave + fr) * g.ldx + g.c0;
+    T* Xw = g.X + (m0 + 16 * JT * wave + fr) * g.ldx + g.c0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 16 * i + F::row_of(lane, r);
@@ -193,9 +197,9 @@ __device__ __forceinline__ void tail_epilogue(const TailArgs<T>& g, int64_t m0, 
         if (16 * i >= w) {                                         // wave-uniform
             continue;
         }
-        acc_t o[2];
+        acc_t o[JT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[j][r] = (T)0;
         const int qa = 16 * i + fr;
@@ -206,16 +210,16 @@ __device__ __forceinline__ void tail_epilogue(const TailArgs<T>& g, int64_t m0, 
                 const int k = 16 * ip + F::row_of(lane, s);
                 const T e = (qa < w && k < w) ? g.E[qa * 128 + k] : (T)0;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) o[j] = F::mfma(e, acc[ip][j][s], o[j]);
+                for (int j = 0; j < JT; ++j) o[j] = F::mfma(e, acc[ip][j][s], o[j]);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = o[j];
+        for (int j = 0; j < JT; ++j) acc[i][j] = o[j];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 16 * i + F::row_of(lane, r);
@@ -223,11 +227,11 @@ __device__ __forceinline__ void tail_epilogue(const TailArgs<T>& g, int64_t m0, 
             }
 }
 
-template <typename T, int NT>
-__global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
+template <typename T, int NT, int JT>
+__global__ __launch_bounds__(256, JT == 2 ? 2 : 3) void tail_cols_kernel(TailArgs<T> g) {
     using acc_t = typename MF<T>::acc_t;
-    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * TAIL_STB];
-    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * tail_stb(JT)];
+    const int64_t m0 = (int64_t)blockIdx.x * (64 * JT);
     acc_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -235,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
-    tail_accumulate<T, NT>(g, m0, 0, (int)(g.c0 / (8 * MF<T>::EPC)), true, acc, smem);
-    tail_epilogue<T>(g, m0, acc);
+    tail_accumulate<T, NT, JT>(g, m0, 0, (int)(g.c0 / (8 * MF<T>::EPC)), true, acc, smem);
+    tail_epilogue<T, JT>(g, m0, acc);
 }
 
 // The same product with the k range cut into nsplit chunks: unit u = chunk * nrb + row block, workgroup b takes units b,
@@ -246,10 +250,10 @@ __global__ __launch_bounds__(256, 2) void tail_cols_kernel(TailArgs<T> g) {
 // half a machine (3.6 - 4.4 TB/s) --, and a rank's 12 500 candidates fill 98 of the 512 slots (1.9 TB/s).  nsplit is chosen
 // by the host so that units / slots sits just below an integer.  Fixed assignment, fixed summation order in
 // tail_finish_kernel: the same bits in every run.
-template <typename T, int NT>
-__global__ __launch_bounds__(256, 2) void tail_part_kernel(TailArgs<T> g) {
+template <typename T, int NT, int JT>
+__global__ __launch_bounds__(256, JT == 2 ? 2 : 3) void tail_part_kernel(TailArgs<T> g) {
     using acc_t = typename MF<T>::acc_t;
-    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * TAIL_STB];
+    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * tail_stb(JT)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int nt = NT;
@@ -266,20 +270,20 @@ __global__ __launch_bounds__(256, 2) void tail_part_kernel(TailArgs<T> g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
         __syncthreads();                                           // the previous unit's last LDS reads are done
-        tail_accumulate<T, NT>(g, (int64_t)rb * 128, kt0, kt1, chunk == g.nsplit - 1, acc, smem);
-        T* dst = g.part + ((int64_t)u * 4 + wave) * nt * 512;
+        tail_accumulate<T, NT, JT>(g, (int64_t)rb * (64 * JT), kt0, kt1, chunk == g.nsplit - 1, acc, smem);
+        T* dst = g.part + ((int64_t)u * 4 + wave) * nt * (256 * JT);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < nt) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < JT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[((i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) dst[((i * JT + j) * 4 + r) * 64 + lane] = acc[i][j][r];
             }
         __builtin_amdgcn_s_waitcnt(0x0F70);                        // the stores have left before the next unit's DMA is counted
     }
 }
-template <typename T>
+template <typename T, int JT>
 __global__ __launch_bounds__(256) void tail_finish_kernel(TailArgs<T> g) {
     using acc_t = typename MF<T>::acc_t;
     const int lane = threadIdx.x & 63;
@@ -294,17 +298,60 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(TailArgs<T> g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
     for (int chunk = 0; chunk < g.nsplit; ++chunk) {               // ascending k: one fixed order of summation
-        const T* src = g.part + (((int64_t)chunk * g.nrb + rb) * 4 + wave) * nt * 512;
+        const T* src = g.part + (((int64_t)chunk * g.nrb + rb) * 4 + wave) * nt * (256 * JT);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < nt) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < JT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * 2 + j) * 4 + r) * 64 + lane];
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * JT + j) * 4 + r) * 64 + lane];
             }
     }
-    tail_epilogue<T>(g, (int64_t)rb * 128, acc);
+    tail_epilogue<T, JT>(g, (int64_t)rb * (64 * JT), acc);
+}
+
+template <typename T, int JT>
+static int tail_dispatch(algp_ctx* c, TailArgs<T>& g, int64_t mpad, int nkt, int w) {
+    // One workgroup per 64 JT rows leaves the last round of workgroups on a part of the machine (or, for a rank's share of
+    // the candidates, never fills it): cut the k range so that the units fill the slots evenly ($ALGP_TAIL_SPLIT=0: never).
+    const int nrb = (int)(mpad / (64 * JT)), slots = JT == 2 ? 512 : 768;
+    int best = 1;
+    {
+        static const bool split_on = !(getenv("ALGP_TAIL_SPLIT") && atoi(getenv("ALGP_TAIL_SPLIT")) == 0);
+        auto eff = [&](int s_) { const double r = (double)s_ * nrb / slots; return r / ceil(r); };
+        double be = eff(1);
+        // worth two launches and the partials' round trip only where the plain launch wastes more than 6 % of the machine
+        for (int s_ = 2; split_on && be < 0.94 && s_ <= 16 && nkt / s_ >= 48; ++s_)
+            if (eff(s_) > be + 0.02) { be = eff(s_); best = s_; }
+    }
+    const int nt = (w + 15) / 16;
+    if (best == 1) {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((tail_cols_kernel<T, 1, JT>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+            case 2: hipLaunchKernelGGL((tail_cols_kernel<T, 2, JT>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+            case 3: hipLaunchKernelGGL((tail_cols_kernel<T, 3, JT>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+            default: hipLaunchKernelGGL((tail_cols_kernel<T, 4, JT>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
+        }
+        ALGP_HIP(hipGetLastError());
+        return ALGP_OK;
+    }
+    ALGP_TRY(ensure(c, c->tailPart, sizeof(T) * (size_t)best * (size_t)nrb * 4 * (size_t)nt * (256 * JT)));
+    g.nsplit = best;
+    g.kt_per = (nkt + best - 1) / best;
+    g.nrb = nrb;
+    g.part = (T*)c->tailPart.p;
+    const dim3 pgrid((unsigned)std::min(slots, best * nrb));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((tail_part_kernel<T, 1, JT>), pgrid, dim3(256), 0, c->cur, g); break;
+        case 2: hipLaunchKernelGGL((tail_part_kernel<T, 2, JT>), pgrid, dim3(256), 0, c->cur, g); break;
+        case 3: hipLaunchKernelGGL((tail_part_kernel<T, 3, JT>), pgrid, dim3(256), 0, c->cur, g); break;
+        default: hipLaunchKernelGGL((tail_part_kernel<T, 4, JT>), pgrid, dim3(256), 0, c->cur, g); break;
+    }
+    ALGP_HIP(hipGetLastError());
+    hipLaunchKernelGGL((tail_finish_kernel<T, JT>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
 }
 
 // X[:, c0 : c0 + w) of the mpad rows of X <- the solution's new columns (see the header); c0 a multiple of 16, w <= 64, the
@@ -335,47 +382,11 @@ int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
     g.kt_per = 0;
     g.nrb = 0;
     g.part = nullptr;
-    // One workgroup per 128 rows leaves the last round of workgroups on a part of the machine (or, for a rank's share of
-    // the candidates, never fills it): cut the k range so that the units fill the 512 slots evenly ($ALGP_TAIL_SPLIT=0: never).
-    const int nrb = (int)(mpad / 128), slots = 512;
     const int nkt = (int)(c0 / (16 / sizeof(T) * 8));
-    int best = 1;
-    {
-        static const bool split_on = !(getenv("ALGP_TAIL_SPLIT") && atoi(getenv("ALGP_TAIL_SPLIT")) == 0);
-        auto eff = [&](int s_) { const double r = (double)s_ * nrb / slots; return r / ceil(r); };
-        double be = eff(1);
-        // worth two launches and the partials' round trip only where the plain launch wastes more than 6 % of the machine
-        for (int s_ = 2; split_on && be < 0.94 && s_ <= 16 && nkt / s_ >= 48; ++s_)
-            if (eff(s_) > be + 0.02) { be = eff(s_); best = s_; }
-    }
     ProfScope ps(c, klass, 2.0 * (double)mpad * (double)c0 * w, sizeof(T) * ((double)mpad * (double)c0 + 64.0 * (double)c0));
-    const int nt = (w + 15) / 16;
-    if (best == 1) {
-        switch (nt) {
-            case 1: hipLaunchKernelGGL((tail_cols_kernel<T, 1>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
-            case 2: hipLaunchKernelGGL((tail_cols_kernel<T, 2>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
-            case 3: hipLaunchKernelGGL((tail_cols_kernel<T, 3>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
-            default: hipLaunchKernelGGL((tail_cols_kernel<T, 4>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
-        }
-        ALGP_HIP(hipGetLastError());
-        return ALGP_OK;
-    }
-    ALGP_TRY(ensure(c, c->tailPart, sizeof(T) * (size_t)best * (size_t)nrb * 4 * (size_t)nt * 512));
-    g.nsplit = best;
-    g.kt_per = (nkt + best - 1) / best;
-    g.nrb = nrb;
-    g.part = (T*)c->tailPart.p;
-    const dim3 pgrid((unsigned)std::min(slots, best * nrb));
-    switch (nt) {
-        case 1: hipLaunchKernelGGL((tail_part_kernel<T, 1>), pgrid, dim3(256), 0, c->cur, g); break;
-        case 2: hipLaunchKernelGGL((tail_part_kernel<T, 2>), pgrid, dim3(256), 0, c->cur, g); break;
-        case 3: hipLaunchKernelGGL((tail_part_kernel<T, 3>), pgrid, dim3(256), 0, c->cur, g); break;
-        default: hipLaunchKernelGGL((tail_part_kernel<T, 4>), pgrid, dim3(256), 0, c->cur, g); break;
-    }
-    ALGP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(tail_finish_kernel<T>, dim3((unsigned)nrb), dim3(256), 0, c->cur, g);
-    ALGP_HIP(hipGetLastError());
-    return ALGP_OK;
+    // $ALGP_TAIL_ROWS=64: 64 candidate rows per workgroup (48 KB of LDS: three workgroups per CU) instead of 128 (72 KB: two)
+    static const bool rows64 = getenv("ALGP_TAIL_ROWS") && atoi(getenv("ALGP_TAIL_ROWS")) == 64;
+    return rows64 ? tail_dispatch<T, 1>(c, g, mpad, nkt, w) : tail_dispatch<T, 2>(c, g, mpad, nkt, w);
 }
 template int tail_cols_launch<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, int64_t, const double*, int64_t, int,
                                       const double*);

@@ -131,7 +131,7 @@ print(json.dumps(out))
 
 def _run5(env_extra):
     env = dict(os.environ)
-    for k in ('ALGP_TAIL_EXACT', 'ALGP_TAIL_STRADDLE', 'ALGP_TAIL_SPLIT', 'ALGP_TAIL_COLS', 'ALGP_Z_IN_PANEL', 'ALGP_FIT_ONE_LAUNCH'):
+    for k in ('ALGP_TAIL_EXACT', 'ALGP_TAIL_STRADDLE', 'ALGP_TAIL_SPLIT', 'ALGP_TAIL_COLS', 'ALGP_TAIL_ROWS', 'ALGP_Z_IN_PANEL', 'ALGP_FIT_ONE_LAUNCH'):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, '-c', _STEP5], env=env, capture_output=True, text=True, timeout=300)
@@ -145,10 +145,10 @@ def default_run5():
 
 
 @pytest.mark.parametrize('switch', ['ALGP_TAIL_EXACT=0', 'ALGP_TAIL_EXACT=0 ALGP_TAIL_STRADDLE=0', 'ALGP_TAIL_SPLIT=0', 'ALGP_TAIL_COLS=0',
-                                    'ALGP_Z_IN_PANEL=0', 'ALGP_FIT_ONE_LAUNCH=0'])
+                                    'ALGP_TAIL_ROWS=64', 'ALGP_TAIL_ROWS=64 ALGP_TAIL_SPLIT=0', 'ALGP_Z_IN_PANEL=0', 'ALGP_FIT_ONE_LAUNCH=0'])
 def test_round5_switch_reproduces_default(default_run5, switch):
     """Every form the tail kernel replaced (16-aligned columns, a pass per 128-column block, one workgroup per 128 rows, the
-    128-column blocks) and z by a substitution launch instead of a row of the panel: the same posterior, log-determinant,
+    128-column blocks), its 64-row workgroups (three per CU), and z by a substitution launch instead of a row of the panel: the same posterior, log-determinant,
     MLL and gradient to rounding.  (Reference: agent.py:210 refits from scratch at every step; models.py:145-158.)"""
     got, ref = _run5(dict(kv.split('=') for kv in switch.split())), default_run5
     assert ref['b']['kept'] == 2260 and ref['c']['kept'] == 2283                      # exactly the appended columns by default
