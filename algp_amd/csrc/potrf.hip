@@ -663,19 +663,27 @@ __global__ __launch_bounds__(512) void trsv_chain_kernel(const T* L, int64_t ld,
 #pragma unroll
     for (int v = 0; v < NR; ++v) acc[v] = (T)0;
     const T* Lrow = L + ((int64_t)i * 128 + r) * ld + q * 32;
+    // Two 32-element buffers per thread (round 5; three before: 254 VGPRs + 16 spilled in fp64): `cur` holds the segment being
+    // multiplied, `nxt` the next one -- the next tile's segment of L or, behind the last tile, this thread's 32 entries of the
+    // inverse of the diagonal block -- and every prefetch is issued BEFORE the wait for the block's flag, so it flies while the
+    // chain's previous block finishes.
     T cur[32], nxt[32];
+    const T* Xrow = invD + (int64_t)i * 128 * 128 + r * 128 + q * 32;
     if (kb0 < i) {
 #pragma unroll
         for (int e = 0; e < 32; ++e) cur[e] = Lrow[(int64_t)kb0 * 128 + e];
-    }
-    // the inverse of the diagonal block: this thread's 32 entries of row r, loaded long before they are needed
-    T xinv[32];
-    {
-        const T* X = invD + (int64_t)i * 128 * 128 + r * 128 + q * 32;
+    } else {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) xinv[e] = X[e];
+        for (int e = 0; e < 32; ++e) cur[e] = Xrow[e];
     }
     for (int j = kb0; j < i; ++j) {
+        if (j + 1 < i) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) nxt[e] = Lrow[(int64_t)(j + 1) * 128 + e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) nxt[e] = Xrow[e];
+        }
         if (tid == 0) {
             bool ok = false;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -697,10 +705,6 @@ __global__ __launch_bounds__(512) void trsv_chain_kernel(const T* L, int64_t ld,
         if (tid < 128) {
 #pragma unroll
             for (int v = 0; v < NR; ++v) zs[v][tid] = __hip_atomic_load(bs[v] + (int64_t)j * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (j + 1 < i) {
-#pragma unroll
-            for (int e = 0; e < 32; ++e) nxt[e] = Lrow[(int64_t)(j + 1) * 128 + e];
         }
         __syncthreads();
 #pragma unroll
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(512) void trsv_chain_kernel(const T* L, int64_t ld,
     for (int v = 0; v < NR; ++v) {
         T s = (T)0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) s += xinv[e] * zs[v][q * 32 + e];
+        for (int e = 0; e < 32; ++e) s += cur[e] * zs[v][q * 32 + e];          // cur: the inverse block's entries by now
         red[v][q][r] = s;
     }
     __syncthreads();
@@ -756,23 +760,34 @@ __global__ __launch_bounds__(512) void trsv_chain_back_kernel(const T* L, int64_
     const int tid = threadIdx.x, cc = tid & 127, q = tid >> 7;
     if (tid == 0) s_i = nblk - 1 - atomicAdd(&ctrl[0], 1);
     __syncthreads();
-    const int i = s_i;
+    const int i = __builtin_amdgcn_readfirstlane(s_i);             // wave-uniform, and told so: scalar address arithmetic below
     if (i < 0) return;
     int* flags = ctrl + 8;
     T acc = (T)0;
-    const T* Lcol = L + (int64_t)(q * 32) * ld + (int64_t)i * 128 + cc;       // row 32 q of a tile in column block i
+    // row 32 q of a tile in column block i: a wave-uniform base (q is: two waves per row quarter) + the lane's column, so that
+    // the 32 row addresses of a tile segment live in scalar registers (as 32 per-lane 64-bit addresses they cost 64 VGPRs:
+    // 256 + 14 spilled in fp64)
+    const int qs = __builtin_amdgcn_readfirstlane(q);
+    const T* Lblk = L + (int64_t)(qs * 32) * ld + (int64_t)i * 128;
+#define Lcol_at(row) (Lblk + (int64_t)(row) * ld)[(unsigned)cc]
+    // two buffers, prefetch before the flag wait, the inverse block's column behind the last tile: as in the forward kernel
     T cur[32], nxt[32];
+    const T* Xcol = invD + (int64_t)i * 128 * 128 + (int64_t)(qs * 32) * 128 + cc;     // column cc of X_ii, rows 32 q ..
     if (i + 1 < nblk) {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) cur[e] = Lcol[((int64_t)(nblk - 1) * 128 + e) * ld];
-    }
-    T xinv[32];                                                    // column cc of X_ii, rows 32 q ..: loaded long before they are needed
-    {
-        const T* X = invD + (int64_t)i * 128 * 128 + (int64_t)(q * 32) * 128 + cc;
+        for (int e = 0; e < 32; ++e) cur[e] = Lcol_at((int64_t)(nblk - 1) * 128 + e);
+    } else {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) xinv[e] = X[e * 128];
+        for (int e = 0; e < 32; ++e) cur[e] = Xcol[e * 128];
     }
     for (int j = nblk - 1; j > i; --j) {
+        if (j - 1 > i) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) nxt[e] = Lcol_at((int64_t)(j - 1) * 128 + e);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) nxt[e] = Xcol[e * 128];
+        }
         if (tid == 0) {
             bool ok = false;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -791,13 +806,12 @@ __global__ __launch_bounds__(512) void trsv_chain_back_kernel(const T* L, int64_
         __syncthreads();
         if (!s_ok) return;                                         // wave-uniform: the launch is being abandoned
         if (tid < 128) zs[tid] = __hip_atomic_load(b + (int64_t)j * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (j - 1 > i) {
-#pragma unroll
-            for (int e = 0; e < 32; ++e) nxt[e] = Lcol[((int64_t)(j - 1) * 128 + e) * ld];
-        }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 32; ++e) acc += cur[e] * zs[q * 32 + e];
+        for (int e = 0; e < 32; ++e) {
+            acc += cur[e] * zs[q * 32 + e];
+            if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight LDS operands live at a time, not thirty-two
+        }
 #pragma unroll
         for (int e = 0; e < 32; ++e) cur[e] = nxt[e];
         __syncthreads();                                           // zs is rewritten in the next round
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(512) void trsv_chain_back_kernel(const T* L, int64_
     {
         T s = (T)0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) s += xinv[e] * zs[q * 32 + e];
+        for (int e = 0; e < 32; ++e) s += cur[e] * zs[q * 32 + e];             // cur: the inverse block's column by now
         red[q][cc] = s;
     }
     __syncthreads();
@@ -817,6 +831,7 @@ __global__ __launch_bounds__(512) void trsv_chain_back_kernel(const T* L, int64_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && i != skip_block) __hip_atomic_store(&flags[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#undef Lcol_at
 }
 
 // control words of a substitution launch (zeroed per launch) and the test hook's arguments
