@@ -889,6 +889,8 @@ def main():
     ap.add_argument('--loop', type=int, default=0, help='K > 0: run config 5\'s active-learning loop for K incremental steps on the --gpus ranks '
                     'instead of the config-4 step (candidates sharded, factor replicated; see loop_mode)')
     ap.add_argument('--loop-field', type=lambda v: tuple(int(x) for x in v.split('x')), default=(250, 200), help='RxC of the loop\'s field (default 250x200 = 50 000 sites)')
+    ap.add_argument('--extra-loop-steps', type=int, default=200, help='with --gpus N > 1 the line also carries extra.c5_loop: config 5\'s loop '
+                    'for this many incremental steps on the N ranks (0 or --no-extras: skipped)')
     ap.add_argument('--cpu-train', type=int, default=6000)
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r05_traffic_pmc.json'))
     args = ap.parse_args()
@@ -1065,6 +1067,21 @@ def main():
     if rank == 0 and world == 1 and want != 'weak' and not args.no_emulation:
         emu = strong_emulation(ctx, _hip, res, args)
 
+    # N > 1: BASELINE config 5 in its stated form as well -- the active-learning loop on the N ranks (every rank takes part)
+    c5_multi = None
+    if world > 1 and not args.no_extras and args.extra_loop_steps > 0:
+        ctx.close()
+        ctx = None
+        largs = argparse.Namespace(**vars(args))
+        largs.loop, largs.cand = args.extra_loop_steps, 100000 if args.cand == 100000 or want == 'weak' else args.cand
+        t0 = time.perf_counter()
+        try:
+            c5_multi = loop_mode(largs, world, rank, local_rank, dist, torch)
+        except Exception as e:                                   # must not cost the headline line (every rank raises alike or none)
+            c5_multi = {'error': '%s: %s' % (type(e).__name__, e)}
+        if c5_multi is not None:
+            c5_multi['leg_wall_s'] = time.perf_counter() - t0
+
     if rank == 0:
         K = args.steps
         w, N, total_c, prof, chol_stats = res['w'], res['N'], res['total_c'], res['prof'], res['chol_stats']
@@ -1205,6 +1222,8 @@ def main():
                 except Exception as e:                         # a failed extra must not cost the headline line
                     extras[name] = {'error': '%s: %s' % (type(e).__name__, e)}
                 extras[name]['leg_wall_s'] = time.perf_counter() - t0
+        if c5_multi is not None:
+            extras['c5_loop'] = c5_multi
         out['extra'] = extras
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w, hyp_vals, args)

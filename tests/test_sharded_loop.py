@@ -237,3 +237,15 @@ def test_bench_loop_mode_two_ranks_on_one_card_equals_one_rank():
     assert two['row_exchanges'] == 6 and two['fallbacks_to_the_triangular_solve'] == 0
     assert two['config']['candidates_per_gpu'] == 4500 and one['config']['candidates_per_gpu'] == 9000
     assert two['value'] > 0 and two['higher_is_better'] is False
+
+
+def test_bench_multi_rank_line_carries_the_loop_as_an_extra():
+    """With --gpus N > 1 the default bench line also times config 5's loop on the N ranks (extra.c5_loop): two ranks on one card
+    over gloo at a reduced size; the headline stays config 4's."""
+    two = _bench(['--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '1', '--train', '2500', '--cand', '9000',
+                  '--loop-field', '60x50', '--extra-loop-steps', '4', '--no-cpu-baseline'], {'ALGP_BENCH_DEVICE': '0'})
+    assert two['n_gpus'] == 2 and two['config']['candidates_total'] == 9000
+    lp = two['extra']['c5_loop']
+    assert 'error' not in lp, lp
+    assert lp['n_gpus'] == 2 and lp['steps'] == 4 and lp['row_exchanges'] == 4 and lp['fallbacks_to_the_triangular_solve'] == 0
+    assert lp['config']['candidates_per_gpu'] == 4500 and lp['value'] > 0
