@@ -319,3 +319,20 @@ def test_c5_50000_points_fp64_consistency():
     assert kept == 49920
     assert c.logdet() - ld0 == pytest.approx(want, rel=1e-8, abs=1e-8)
     c.close()
+
+
+def test_c5_one_rank_of_eight_of_the_loop_at_full_size():
+    """BASELINE config 5 in its stated form as ONE of its eight ranks sees it, at full size: N0 = 50 000 train rows (replicated
+    factor), the rank's 12 500 of the 100 000 candidates, three planning steps of the active-learning loop (reference
+    agent.py:125-229 with the candidate loop of :313-354 sharded) through algp_factorize_update (collective: agreement word +
+    the row exchange) -> algp_solve_candidates_update -> algp_greedy_sharded, the seven absent ranks fabricated from a
+    one-rank context that runs the same loop in lockstep (bench.c5_rank_of_8: the rows of L the other ranks own are the
+    one-rank factor's own new rows, the winners' rows its picks').  bench.c5_rank_of_8 itself asserts, at every step, that the
+    rank's picks are the one-rank loop's and that no factor update fell back to the triangular solve; here also: every
+    update went through the exchange, and the step is faster than the one-rank step it replaces."""
+    import bench
+    out = bench.c5_rank_of_8(_hip, 0, 4, steps=3, ranks=(5,))
+    r = out['ranks']['5']
+    assert r['row_exchanges'] == 3 and r['fallbacks'] == 0 and r['candidates'] == 12500
+    assert out['new_train_rows_per_step_median'] >= 28 and 1 <= out['rows_per_rank_in_the_exchange_median'] <= 16
+    assert r['ms_per_step_median'] < 11.0, r                              # the one-GPU step takes 11 ms

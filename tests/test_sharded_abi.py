@@ -305,3 +305,35 @@ def test_bench_plain_launch_with_two_ranks_on_one_card():
     assert 'algp_greedy_sharded' in two['config']['collective']
     assert two['weak_scaling']['candidates_total'] == 40000 and two['weak_scaling']['value'] > 0
     assert one['host_syncs_per_step'] <= 4 + 6            # 4 picks + the fit/solve's own
+
+
+def test_comm_set_owners_argument_checks(ctx):
+    """algp_comm_set_owners: needs a communicator and a pool, one entry per pool site, ranks inside the communicator (-1 = nobody);
+    NULL clears the map; a map of one rank changes nothing (the factor update stays local, counters untouched)."""
+    X, N, var, cand = _field()
+    _setup(ctx, X, N, var, cand)
+    with pytest.raises(ValueError):
+        ctx.comm_set_owners(np.zeros(len(X), np.int32))             # no communicator attached
+    ctx.comm_init_host(3, 1, lambda b: b * 3)
+    try:
+        with pytest.raises(ValueError):
+            ctx.comm_set_owners(np.zeros(len(X) - 1, np.int32))     # one entry per pool site
+        bad = np.zeros(len(X), np.int32)
+        bad[5] = 3
+        with pytest.raises(ValueError):
+            ctx.comm_set_owners(bad)                                # rank outside the communicator
+        ok = (np.arange(len(X)) % 3).astype(np.int32)
+        ok[7] = -1                                                  # nobody holds site 7 as a candidate: allowed
+        ctx.comm_set_owners(ok)
+        ctx.comm_set_owners(None)                                   # cleared
+    finally:
+        ctx.comm_destroy()
+    ctx.comm_init_host(1, 0, lambda b: b)
+    try:
+        ctx.comm_set_owners(np.zeros(len(X), np.int32))
+        idx = np.r_[np.arange(N), cand[-3:]]
+        ctx.set_train(idx, np.zeros(len(idx)), np.r_[var, np.full(3, 1.0)])
+        assert ctx.factorize(incremental=True) == N // 128 * 128
+        assert ctx.counter(3) == 0 and ctx.counter(4) == 0          # one rank: no exchange, no agreed fall-back
+    finally:
+        ctx.comm_destroy()
