@@ -60,6 +60,60 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const T* Vt, int64_t r
     }
 }
 
+// Dot product of a row with w in an order that sixteen waves together or one wave alone can follow, bit for bit: vector v
+// (16 bytes) belongs to virtual lane v mod 1024, a virtual lane adds its vectors in ascending order (fused multiply-adds,
+// element by element), each of the sixteen virtual waves folds its 64 lanes with the shuffle tree, and the sixteen partial
+// sums are added left to right.  The lazy refresh of ONE row (the pick's own row, the best stale row: latency-bound, 117 us
+// for a row of 50 000 with one wave) runs the sixteen virtual waves on sixteen real ones; the sweeps over many rows keep a
+// wave per row with sixteen accumulators.  The elements behind the last full vector go to virtual wave 0.
+template <typename T>
+__device__ __forceinline__ void dot_vec(T& acc, const T* row, const T* w, int64_t v) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const vec_t x = *reinterpret_cast<const vec_t*>(row + v * VEC);
+    const vec_t y = *reinterpret_cast<const vec_t*>(w + v * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc = __builtin_fma(x[e], y[e], acc);
+}
+template <typename T>
+__device__ __forceinline__ T dot_tree(T s) {
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    return s;
+}
+// virtual wave vw's partial sum (valid in lane 0)
+template <typename T>
+__device__ __forceinline__ T row_dot_virtual_wave(const T* row, const T* w, int64_t ncols, int lane, int vw) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t nvec = ncols / VEC;
+    T s = (T)0;
+    for (int64_t v = vw * 64 + lane; v < nvec; v += 1024) dot_vec<T>(s, row, w, v);
+    const int64_t t = nvec * VEC + lane;
+    if (vw == 0 && t < ncols) s = __builtin_fma(row[t], w[t], s);
+    return dot_tree<T>(s);
+}
+// the whole dot product by one wave (valid in lane 0)
+template <typename T>
+__device__ __forceinline__ T row_dot_one_wave(const T* row, const T* w, int64_t ncols, int lane) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t nvec = ncols / VEC;
+    T acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = (T)0;
+    for (int64_t base = 0; base < nvec; base += 1024) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t v = base + k * 64 + lane;
+            if (v < nvec) dot_vec<T>(acc[k], row, w, v);
+        }
+    }
+    const int64_t t = nvec * VEC + lane;
+    if (t < ncols) acc[0] = __builtin_fma(row[t], w[t], acc[0]);
+    T s = dot_tree<T>(acc[0]);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += dot_tree<T>(acc[k]);
+    return s;
+}
+
 // Column window [c0, c1) (multiples of 128) of every row: sum v^2, sum v u, sum v w; accumulate != 0 adds to the
 // outputs.  Used by the incremental candidate solve: the sums over the kept columns of V^T are carried from
 // step to step and only the new columns are read (the posterior mean needs V.z with z = u - ybar w).
@@ -396,7 +450,7 @@ template int gather_rows_launch<float>(algp_ctx*, const float*, int64_t, const i
 // (information gain is submodular), so a utility computed before the last picks is an upper bound.  After
 // a pick only the rows that can still win are brought up to date: the best stale row first (its fresh
 // utility becomes the threshold), then every stale row whose bound reaches the threshold.  A refresh
-// applies the missing picks in order with exactly the arithmetic of the full pass (wave_row_reduce +
+// applies the missing picks in order with exactly the arithmetic of the full pass (row_dot_* +
 // pick_bprime), so picks and values equal the full pass bit for bit; it costs one row of V^T per pick
 // instead of a sweep over all M rows.
 //   mode 0: row `pos` only (grid = 1 block)   mode 1: alive stale rows with scores >= scores[pos]
@@ -404,8 +458,8 @@ template int gather_rows_launch<float>(algp_ctx*, const float*, int64_t, const i
 // pos_dev != null: the row is the one an argmax kernel has just left on the device (*pos_dev; < 0 = no row, nothing to
 // do), so that argmax -> refresh -> refresh -> argmax is one stream-ordered chain without a host round trip.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DP>
-__global__ __launch_bounds__(256) void lazy_refresh_kernel(int64_t M, int mode, int64_t pos, const int64_t* pos_dev,
+template <typename T, int DP, bool COOP>
+__global__ __launch_bounds__(COOP ? 1024 : 256) void lazy_refresh_kernel(int64_t M, int mode, int64_t pos, const int64_t* pos_dev,
                                                            const LazyPick* picks,
                                                            int npicks, const int* ckind, const int64_t* cidx,
                                                            const T* Xs, const T* Cp, int64_t n_pool, int kernel, T os,
@@ -413,19 +467,47 @@ __global__ __launch_bounds__(256) void lazy_refresh_kernel(int64_t M, int mode, 
                                                            int* fresh, const unsigned char* alive, double* scores,
                                                            double ss, double delta) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * 4;
     if (pos_dev) {
         pos = *pos_dev;
         if (pos < 0 && mode != 2) return;
     }
-    const double thr = (mode == 1) ? scores[pos] : 0.0;        // row pos is up to date in mode 1: never rewritten here
-    for (int64_t j0 = wave; j0 < M; j0 += nw) {
-        int64_t j = j0;
-        if (mode == 0) {
-            if (j0 != 0) break;
-            j = pos;
+    if (COOP) {
+        // one row (mode 0: row pos; mode 2 with M = 1: row 0), sixteen waves: wave w is virtual wave w of the dot product
+        __shared__ T red[16];
+        const int wv = threadIdx.x >> 6;
+        const int64_t j = (mode == 0) ? pos : 0;
+        const int f = fresh[j];
+        if (f >= npicks) return;
+        const bool unit = ckind[j] >= 0;
+        const int64_t pj = cidx[j];
+        T* row = Vt + j * ldv;
+        T d = dstat[j];
+        for (int q = f; q < npicks; ++q) {
+            const LazyPick pk = picks[q];
+            const T part = row_dot_virtual_wave<T>(row, prevrows + (int64_t)q * ldv, pk.ncols, lane, wv);
+            if (lane == 0) red[wv] = part;
+            __syncthreads();
+            T sd = red[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) sd += red[k];
+            const T bp = pick_bprime<T, DP>(unit, pj, Xs, Cp, n_pool, pk.pool_idx, (int)pk.in_train, kernel, os, noise);
+            const T r = (bp - sd) * (T)pk.scale;
+            d += unit ? r * r : -(r * r);
+            if (threadIdx.x == 0) row[pk.ncols] = r;
+            __threadfence();                                   // the next pick's dot product reads this entry
+            __syncthreads();
         }
+        if (threadIdx.x == 0) {
+            dstat[j] = d;
+            fresh[j] = npicks;
+            scores[j] = alive[j] ? entropy_utility((double)d, unit, ss, delta) : -INFINITY;
+        }
+        return;
+    }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const double thr = (mode == 1) ? scores[pos] : 0.0;        // row pos is up to date in mode 1: never rewritten here
+    for (int64_t j = wave; j < M; j += nw) {
         const int f = fresh[j];
         if (f >= npicks) continue;
         if (mode == 1 && (!alive[j] || !(scores[j] >= thr))) continue;
@@ -435,8 +517,7 @@ __global__ __launch_bounds__(256) void lazy_refresh_kernel(int64_t M, int mode, 
         T d = dstat[j];
         for (int q = f; q < npicks; ++q) {
             const LazyPick pk = picks[q];
-            T s2, sd;
-            wave_row_reduce<T, true, false>(row, prevrows + (int64_t)q * ldv, pk.ncols, lane, s2, sd);
+            T sd = row_dot_one_wave<T>(row, prevrows + (int64_t)q * ldv, pk.ncols, lane);
             sd = __shfl(sd, 0, 64);
             const T bp = pick_bprime<T, DP>(unit, pj, Xs, Cp, n_pool, pk.pool_idx, (int)pk.in_train, kernel, os, noise);
             const T r = (bp - sd) * (T)pk.scale;
@@ -458,16 +539,23 @@ int lazy_refresh_launch(algp_ctx* c, int64_t M, int mode, int64_t pos, const Laz
                         const T* prevrows, int64_t ldv, T* Vt, T* dstat, int* fresh, const unsigned char* alive,
                         double* scores, double ss, double delta, const int64_t* pos_dev) {
     if (M <= 0 || npicks <= 0) return ALGP_OK;
-    int64_t g = (mode == 0) ? 1 : (M + 3) / 4;
+    const bool coop = (mode == 0 || (mode == 2 && M == 1));      // one row: sixteen waves share its dot products
+    int64_t g = coop ? 1 : (M + 3) / 4;
     if (g > 65536) g = 65536;
     ProfScope ps(c, ALGP_PROF_ROWS, 0.0, 13.0 * M);
-    dim3 grid((unsigned)g), blk(256);
-#define ALGP_LR(DPV)                                                                                              \
-    hipLaunchKernelGGL((lazy_refresh_kernel<T, DPV>), grid, blk, 0, c->cur, M, mode, pos, pos_dev, picks, npicks, ckind, \
+    dim3 grid((unsigned)g), blk(coop ? 1024 : 256);
+#define ALGP_LR(DPV, CO)                                                                                          \
+    hipLaunchKernelGGL((lazy_refresh_kernel<T, DPV, CO>), grid, blk, 0, c->cur, M, mode, pos, pos_dev, picks, npicks, ckind, \
                        cidx, Xs, Cp, n_pool, kernel, os, noise, prevrows, ldv, Vt, dstat, fresh, alive, scores, ss, delta)
-    if (DP == 2) ALGP_LR(2);
-    else if (DP == 4) ALGP_LR(4);
-    else ALGP_LR(8);
+#define ALGP_LR2(DPV)                                                                                             \
+    do {                                                                                                          \
+        if (coop) ALGP_LR(DPV, true);                                                                             \
+        else ALGP_LR(DPV, false);                                                                                 \
+    } while (0)
+    if (DP == 2) ALGP_LR2(2);
+    else if (DP == 4) ALGP_LR2(4);
+    else ALGP_LR2(8);
+#undef ALGP_LR2
 #undef ALGP_LR
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
