@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void pack_row_kernel(const int64_t* pos, const
 // out = (utility, pool index, owning rank, status, first rank with a non-zero status): the first maximum in rank order
 // over the ranks that have a candidate -- a NaN utility never wins (the local argmax skips NaN as well), -inf does when
 // nothing else is on offer -- and the largest status word (error codes are >= 2, so they outrank "one more round")
-__global__ void first_max_kernel(const char* payloads, int64_t stride, int nranks, double* out) {
+__host__ __device__ inline void first_max_reduce(const char* payloads, int64_t stride, int nranks, double* out) {
     double bv = -INFINITY, bi = -1.0, br = -1.0, st = 0.0, bad = -1.0;
     for (int r = 0; r < nranks; ++r) {
         const double* t = (const double*)(payloads + (int64_t)r * stride);
@@ -136,6 +136,11 @@ __global__ void first_max_kernel(const char* payloads, int64_t stride, int nrank
     out[2] = br;
     out[3] = st == st ? st : (double)ALGP_ERR_HIP;
     out[4] = bad;
+}
+// the RCCL transport and the one-rank case reduce where the payloads are, on the device; the host transport has them in
+// host memory when the caller's gather returns and reduces there (pick_exchange)
+__global__ void first_max_kernel(const char* payloads, int64_t stride, int nranks, double* out) {
+    first_max_reduce(payloads, stride, nranks, out);
 }
 
 int comm_unique_id(void* out128, std::string* why) {
@@ -240,8 +245,8 @@ void comm_destroy(algp_ctx* c) {
 
 // The exchange of one pick.  (val_dev, pos_dev): the local argmax as the kernels before left it on the device (null: this
 // rank has no candidate to offer); status: 0 or the ALGP_ERR_* code this rank failed with while preparing it.  Everything
-// is stream-ordered; the single synchronisation (RCCL transport; the host transport needs two more to stage the payloads
-// through host memory) is the read-back of rec5 = (utility, pool index, owner, status, first rank with a non-zero
+// is stream-ordered; the single synchronisation (RCCL transport: the read-back of the record; host transport: the payload's
+// way down to host memory, where the record is then computed) is the read-back of rec5 = (utility, pool index, owner, status, first rank with a non-zero
 // status), identical on every rank.  *winner_payload: where the owner's payload sits in this rank's gather buffer (device).
 // No rank-local failure returns before the collective has been issued: a pack launch that fails turns into this rank's
 // status word (written from the host); only a failure of the transport itself (the collective call, the copies around the
@@ -300,7 +305,15 @@ static int pick_exchange(algp_ctx* c, const double* val_dev, const int64_t* pos_
         c->n_syncs++;
         const int rc = c->host_gather(c->host_gather_user, hs, hr, (int64_t)pb);
         if (rc != 0) return fail(c, ALGP_ERR_HIP, "greedy_sharded: the caller's all-gather returned " + std::to_string(rc));
-        ALGP_HIP(hipMemcpyAsync(all, hr, pb * (size_t)nr, hipMemcpyHostToDevice, c->stream));
+        // the payloads are in host memory: the reduction of first_max_kernel runs here, and only the winner's payload (its
+        // statistic and its row of V^T, what commit_enqueue reads) goes back up -- one row instead of one per rank, no
+        // read-back of the record, one synchronisation less per pick
+        first_max_reduce(hr, (int64_t)pb, nr, rec5);
+        const int owner = (int)rec5[2];
+        const bool have = pb > 32 && owner >= 0 && owner < nr;
+        if (have) ALGP_HIP(hipMemcpyAsync(all + (size_t)owner * pb, hr + (size_t)owner * pb, pb, hipMemcpyHostToDevice, c->stream));
+        if (winner_payload) *winner_payload = have ? all + (size_t)owner * pb : nullptr;
+        return ALGP_OK;
     } else {
         gathered = own;                                  // one rank: the same reduction over its own payload
     }

@@ -407,7 +407,8 @@ template int uw_init_launch<float>(algp_ctx*, float*, float*, const float*, int6
 template int uw_combine_launch<double>(algp_ctx*, double*, const double*, const double*, double, int64_t);
 template int uw_combine_launch<float>(algp_ctx*, float*, const float*, const float*, float, int64_t);
 
-// dst[r][0:ncols] = src[src_row[r]][0:ncols], or zeros where src_row[r] < 0 (one workgroup per row).
+// dst[r][0:ncols] = src[src_row[r]][0:ncols], or zeros where src_row[r] < 0 (one workgroup per row and 2048 columns: the
+// row exchange of the sharded loop packs a handful of rows of 50 000).
 // With lrow: rows with lrow[r] >= 0 are  Lb[lrow[r]][0:ncols] - lscale[r] * src[src_row[r]][0:ncols]
 // (a second measurement of a site that already is train row lrow[r], see vt_rows_for_new_sites in api.hip).
 template <typename T>
@@ -416,18 +417,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* src, int64_t 
                                                           const T* Lb, int64_t ldl) {
     const int64_t r = blockIdx.x, sr = src_row[r];
     T* d = dst + r * ldd;
+    const int64_t k0 = (int64_t)blockIdx.y * 2048 + threadIdx.x;
+    ncols = ncols < ((int64_t)blockIdx.y + 1) * 2048 ? ncols : ((int64_t)blockIdx.y + 1) * 2048;
     if (sr < 0) {
-        for (int64_t k = threadIdx.x; k < ncols; k += 256) d[k] = (T)0;
+        for (int64_t k = k0; k < ncols; k += 256) d[k] = (T)0;
     } else if (lrow && lrow[r] >= 0) {
         const T* sp = src + sr * lds;
         const int64_t lr = lrow[r];
         const T* lp = Lb + lr * ldl;
         const T sc = lscale[r];
         // row lr of L ends at its diagonal (the strict upper part of a diagonal block is scratch)
-        for (int64_t k = threadIdx.x; k < ncols; k += 256) d[k] = (k <= lr ? lp[k] : (T)0) - sc * sp[k];
+        for (int64_t k = k0; k < ncols; k += 256) d[k] = (k <= lr ? lp[k] : (T)0) - sc * sp[k];
     } else {
         const T* sp = src + sr * lds;
-        for (int64_t k = threadIdx.x; k < ncols; k += 256) d[k] = sp[k];
+        for (int64_t k = k0; k < ncols; k += 256) d[k] = sp[k];
     }
 }
 
@@ -435,7 +438,7 @@ template <typename T>
 int gather_rows_launch(algp_ctx* c, const T* src, int64_t lds, const int64_t* src_row, T* dst, int64_t ldd, int64_t nrows,
                        int64_t ncols, const int64_t* lrow, const T* lscale, const T* Lb, int64_t ldl) {
     if (nrows <= 0 || ncols <= 0) return ALGP_OK;
-    hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((unsigned)nrows), dim3(256), 0, c->cur, src, lds, src_row, dst, ldd, ncols,
+    hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((unsigned)nrows, (unsigned)((ncols + 2047) / 2048)), dim3(256), 0, c->cur, src, lds, src_row, dst, ldd, ncols,
                        lrow, lscale, Lb, ldl);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;

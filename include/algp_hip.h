@@ -227,7 +227,8 @@ int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen
  *   calls it).  RCCL is opened with dlopen here; without it these return ALGP_ERR_HIP and nothing else is affected.
  * algp_comm_init_host: the same loop over a transport the CALLER owns (MPI, gloo, shared memory): `fn(user, send, recv,
  *   bytes_per_rank)` must all-gather `bytes_per_rank` bytes of host memory in rank order and return 0; it is called
- *   once per pick (twice in the rare extra round) by every rank; two stream synchronisations per pick instead of one.
+ *   once per pick (twice in the rare extra round) by every rank; one stream synchronisation per pick, in front of it
+ *   (the winner is then chosen on the host and only its row goes back to the device).
  *   This is also how two ranks can share one card.
  * Both reserve the exchange's buffers for the current train set; algp_set_train re-reserves them when its size changes.
  * algp_greedy_sharded: k picks (entropy criterion; the MI criterion does not shard).  Per pick, stream-ordered and with

@@ -100,15 +100,16 @@ def test_one_host_round_trip_per_pick(ctx):
     got = ctx.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 6)
     assert ctx.sync_count() - s0 == 6
     assert [int(p) for p in got] == [int(p) for p in want]
-    # the same chain through algp_greedy_sharded with a host transport of one rank: 1 record + 1 in front of the caller's
-    # gather (the payload has to be in host memory; the way back up is an asynchronous copy from pinned staging)
+    # the same chain through algp_greedy_sharded with a host transport of one rank: ONE, in front of the caller's gather (the
+    # payload has to be in host memory; the winner record is then computed there, and the winner's row goes back up as an
+    # asynchronous copy from pinned staging)
     ctx.comm_init_host(1, 0, lambda b: b)
     try:
         ctx.factorize()
         ctx.solve_candidates()
         s0 = ctx.sync_count()
         got2, gut = ctx.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, 6, want_utilities=True)
-        assert ctx.sync_count() - s0 == 2 * 6
+        assert ctx.sync_count() - s0 == 6
         assert [int(p) for p in got2] == [int(p) for p in want]
         for p in range(6):
             assert gut[p] == np.nanmax(ut[p])
