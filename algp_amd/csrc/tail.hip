@@ -10,7 +10,7 @@
 // candidates) on the matrix cores at full tile width, 24 ms where the data take 8 to stream.  Columns left of c0 do not
 // change when rows are appended (L's old rows do not), so only [c0, c1) is computed here, as a 64-wide product that is
 // HBM-bound by construction: a workgroup owns 128 candidate rows, streams them once through a three-stage LDS-DMA
-// pipeline (128-byte row pieces, see the kernel) against the 64 new rows of L, and finishes the columns in its
+// pipeline (128-byte row pieces, see the kernel) against the new rows of L (32 of them, or all 64), and finishes the columns in its
 // epilogue with the trailing block of the tail's explicit inverse (for a lower-triangular D, inv(D)[S, S] = inv(D[S, S])
 // for every diagonal range S): the accumulator of the first product is, as it lies in registers, the B operand of the
 // second (MFMA layouts, mfma.h), so nothing goes through LDS in between.
@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace algp {
 
@@ -42,22 +43,31 @@ struct TailArgs {
     T* part;
 };
 
-constexpr int TAIL_NST = 3;
-constexpr int tail_stb(int JT) { return 8192 + 8192 * JT; }      // a stage: 64 rows of L + 64 JT rows of V^T, 128 bytes each
+// a stage: 32 NL rows of L (NL = 1 while the new columns fit two 16-row tiles -- the usual append of ~30 rows -- else 2: all 64)
+// + 64 JT rows of V^T, 128 bytes each
+constexpr int tail_nl(int NT) { return NT <= 2 ? 1 : 2; }
+constexpr int tail_stb(int NT, int JT) { return 4096 * tail_nl(NT) + 8192 * JT; }
+// stages: three -- one being read, one or two k-tiles in flight.  (Four, where the small stage allows them at the same
+// occupancy, were measured: 7.74 against 7.77 ms for 32 new columns over config 5's 40 GB; so were 64-row workgroups at
+// four per CU against 128-row ones at two: 7.77 both.  What is left above the 6.75 ms the same kernel takes with its
+// products removed does not respond to deeper prefetch or more waves.)
+constexpr int tail_nst(int NT, int JT) { return 3; }
+// workgroups per CU: 160 KB of LDS
+constexpr int tail_occ(int NT, int JT) { return (160 * 1024) / (tail_nst(NT, JT) * tail_stb(NT, JT)); }
 
 // acc += L[c0 .. c0 + 64, k-tiles [kt0, kt1)] (x) X[m0 .. m0 + 128, the same k-tiles]^T for the workgroup's 128 candidate rows;
 // with_ktail: the fp32 half tile behind the last full one as well.  Every wave of the workgroup calls it with the same range.
 // NT: the 16-row tiles of L that carry new columns (ceil(w / 16)), a compile-time constant: the products of a k-tile are one
 // straight run of MFMAs in which consecutive instructions never share an accumulator.
-// JT: 16-candidate tiles per wave -- the workgroup owns 64 JT candidate rows (JT = 2: 72 KB of LDS, two workgroups per CU;
-// JT = 1: 48 KB, three).
+// JT: 16-candidate tiles per wave -- the workgroup owns 64 JT candidate rows (JT = 2: 60 or 72 KB of LDS, two workgroups
+// per CU; JT = 1: 36 or 48 KB, four or three).
 template <typename T, int NT, int JT>
 __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0, int kt0, int kt1, bool with_ktail,
                                                 typename MF<T>::acc_t (&acc)[4][2], char* smem) {
     // k-tiles of 128 bytes per row (the GEMM's are 64): this kernel lives on HBM bandwidth, and with 64-byte pieces of
     // 128 x 512 different rows in flight it reached 2.7 TB/s (14.6 ms for the 40 GB of config 5) -- every piece opens a
-    // DRAM page of its own.  Three stages of 24 KB (8 KB of L rows + 16 KB of V^T rows), two k-tiles in flight.
-    constexpr int NST = TAIL_NST, STB = tail_stb(JT);
+    // DRAM page of its own.  Three stages of 20 / 24 KB (4 / 8 KB of L rows + 16 KB of V^T rows), one or two k-tiles in flight.
+    constexpr int NST = tail_nst(NT, JT), NL = tail_nl(NT), STB = tail_stb(NT, JT), AB = 4096 * NL;
     using F = MF<T>;
     using chunk_t = typename F::chunk_t;
     constexpr int EPC = F::EPC;
@@ -67,13 +77,13 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // DMA: one instruction moves 8 rows x 128 bytes; lane l -> row l >> 3 of the group, LDS slot l & 7.  LDS image
     // [row][8 slots of 16 B], slot = chunk ^ ((row >> 1) & 7): the 16 rows a quarter-wave reads at one chunk index fall
-    // into 16 different 16-byte bank groups.  Wave w stages rows 16 w .. 16 w + 15 of L and 32 w .. 32 w + 31 of V^T.
+    // into 16 different 16-byte bank groups.  Wave w stages rows 8 NL w .. 8 NL (w + 1) - 1 of L and 16 JT w .. of V^T.
     const int r8 = lane >> 3, slot = lane & 7;
-    int lr[2];
-    const T* Lg[2];
+    int lr[NL];
+    const T* Lg[NL];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 16 * wave + 8 * i + r8;                    // row of the 64-row L part
+    for (int i = 0; i < NL; ++i) {
+        const int row = 8 * NL * wave + 8 * i + r8;                // row of the 32 NL-row L part
         lr[i] = row < g.lrows_valid ? row : g.lrows_valid - 1;     // never read beyond the factor's rows; such rows are masked below
         Lg[i] = g.Lrows + (int64_t)lr[i] * g.ldl + (slot ^ ((row >> 1) & 7)) * EPC;
     }
@@ -84,10 +94,10 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
         Xg[i] = g.X + (m0 + row) * g.ldx + (slot ^ ((row >> 1) & 7)) * EPC;
     }
     auto stage = [&](int st, int kt) {
-        char* As = smem + st * STB + wave * 2048;
-        char* Bs = smem + st * STB + 8192 + wave * (2048 * JT);
+        char* As = smem + st * STB + wave * (1024 * NL);
+        char* Bs = smem + st * STB + AB + wave * (2048 * JT);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_vp)(Lg[i] + (int64_t)kt * BK), (lds_vp)(As + i * 1024), 16, 0, 0);
+        for (int i = 0; i < NL; ++i) __builtin_amdgcn_global_load_lds((glb_vp)(Lg[i] + (int64_t)kt * BK), (lds_vp)(As + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2 * JT; ++i) __builtin_amdgcn_global_load_lds((glb_vp)(Xg[i] + (int64_t)kt * BK), (lds_vp)(Bs + i * 1024), 16, 0, 0);
     };
@@ -95,54 +105,82 @@ __device__ __forceinline__ void tail_accumulate(const TailArgs<T>& g, int64_t m0
     // chunk 4 h + fg of row (16 t + fr): slot = (4 h + fg) ^ ((row >> 1) & 7), and (row >> 1) & 7 = (fr >> 1) for every tile
     const int sw = (fr >> 1) & 7;
     const int aoff0 = fr * 128 + ((fg ^ sw) << 4), aoff1 = fr * 128 + (((4 + fg) ^ sw) << 4);
-    const int boff0 = 8192 + (16 * JT * wave + fr) * 128 + ((fg ^ sw) << 4), boff1 = 8192 + (16 * JT * wave + fr) * 128 + (((4 + fg) ^ sw) << 4);
+    const int boff0 = AB + (16 * JT * wave + fr) * 128 + ((fg ^ sw) << 4), boff1 = AB + (16 * JT * wave + fr) * 128 + (((4 + fg) ^ sw) << 4);
 
-    // ALL three stages are in flight: a stage is refilled as soon as every wave holds its fragments in registers (the
-    // second barrier), not one iteration later behind the slowest wave's MFMAs.  With two k-tiles in flight and the
-    // refill issued after the products, the time per k-tile was (memory time) + (MFMA time), not their maximum: 6.9 / 8.4 /
-    // 10.2 / 12.3 ms for 16 / 32 / 48 / 64 new columns over the 40 GB of config 5 (tools/tail_sweep.py).
-#pragma unroll
-    for (int t = 0; t < NST; ++t)
-        if (kt0 + t < kt1) stage(t, kt0 + t);
-    int st = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int ahead = kt1 - 1 - kt;                             // k-tiles behind this one that have been issued: min(2, ahead)
-        // this tile landed, two may fly: 2 + 2 JT DMA instructions per tile and wave
-        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(JT == 2 ? 0x0F7C : 0x0F78);         // vmcnt(12 | 8)
-        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(JT == 2 ? 0x0F76 : 0x0F74);    // vmcnt(6 | 4)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* base = smem + st * STB;
-        chunk_t a0[NT], a1[NT], b0[JT], b1[JT];
+    // One barrier per k-tile, the fragments of tile kt + 1 read from LDS while the products of tile kt run (two register
+    // sets): behind the barrier of step kt every wave holds tile kt in registers (its stage is free: refilled at once with
+    // tile kt + 3) and tile kt + 1 has landed for everybody (read now, multiplied in the next step).  Round 5's first form
+    // read a tile's fragments, waited for them, passed a second barrier, refilled and only then multiplied: with every
+    // load served from cache it still took 6.9 ms for 32 new columns over config 5's 40 GB (4.1 ms of MFMA work; 2.8 ms
+    // with the products removed as well) -- the matrix pipe idled through the LDS latency and two barriers per 16 MFMAs,
+    // and the kernel was bound by that as much as by HBM (6.8 ms with the products removed: 5.9 TB/s).
+    chunk_t fa[2][2][NT], fb[2][2][JT];                            // [register set][half of the k-tile][tile]
+    auto read_frags = [&](auto set_c, int st_) {
+        constexpr int set = decltype(set_c)::value;
+        const char* base = smem + st_ * STB;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            a0[i] = *reinterpret_cast<const chunk_t*>(base + aoff0 + i * 2048);
-            a1[i] = *reinterpret_cast<const chunk_t*>(base + aoff1 + i * 2048);
+            fa[set][0][i] = *reinterpret_cast<const chunk_t*>(base + aoff0 + i * 2048);
+            fa[set][1][i] = *reinterpret_cast<const chunk_t*>(base + aoff1 + i * 2048);
         }
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            b0[j] = *reinterpret_cast<const chunk_t*>(base + boff0 + j * 2048);
-            b1[j] = *reinterpret_cast<const chunk_t*>(base + boff1 + j * 2048);
+            fb[set][0][j] = *reinterpret_cast<const chunk_t*>(base + boff0 + j * 2048);
+            fb[set][1][j] = *reinterpret_cast<const chunk_t*>(base + boff1 + j * 2048);
         }
-        if (kt + NST < kt1) {                                       // wave-uniform
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragments are in registers ...
-            __builtin_amdgcn_s_barrier();                           // ... and so are everybody's: the stage is free
-            asm volatile("" ::: "memory");
-            stage(st, kt + NST);
-        }
+    };
+    // NL + 2 JT DMA instructions per tile and wave
+    auto wait_landed = [&](int flying) {                           // all of this wave's DMA but the last `flying` tiles'
+        constexpr int NI = NL + 2 * JT;                            // instructions per tile; vmcnt: bits 3:0 and 15:14 of the immediate
+#define ALGP_VMCNT(n) (0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+        if (flying >= 3) __builtin_amdgcn_s_waitcnt(ALGP_VMCNT(3 * NI));
+        else if (flying == 2) __builtin_amdgcn_s_waitcnt(ALGP_VMCNT(2 * NI));
+        else if (flying == 1) __builtin_amdgcn_s_waitcnt(ALGP_VMCNT(NI));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0)
+#undef ALGP_VMCNT
+    };
+    auto products = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
 #pragma unroll
-            for (int j = 0; j < JT; ++j)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a0[i][e], b0[j][e], acc[i][j]);
+                for (int j = 0; j < JT; ++j)
 #pragma unroll
-            for (int j = 0; j < JT; ++j)
-#pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(a1[i][e], b1[j][e], acc[i][j]);
+                    for (int i = 0; i < NT; ++i) acc[i][j] = F::mfma(fa[set][h][i][e], fb[set][h][j][e], acc[i][j]);
         }
-        st = (st + 1 == NST) ? 0 : st + 1;
+    };
+    // step kt: set `cur` holds tile kt, stage st0 held it; tile kt + 1 lies in stage st1.  (Spreading the refill's DMA
+    // instructions and the LDS reads over the products, one behind each MFMA, was measured as well: no faster -- 8.07 against
+    // 7.89 ms -- and 60 more registers.)
+    auto step = [&](auto cur_c, auto nxt_c, int kt, int st0, int st1) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): tile kt is in this wave's registers (the builtin, not
+                                                                    // inline asm: the compiler's own wait insertion must see it, or it
+                                                                    // waits again in front of the products -- for tile kt + 1's reads too)
+        wait_landed(min(NST - 2, max(0, kt1 - 2 - kt)));            // tile kt + 1 has landed; tiles kt + 2 .. kt + NST - 1 may fly
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NST < kt1) stage(st0, kt + NST);                   // wave-uniform
+        if (kt + 1 < kt1) read_frags(nxt_c, st1);
+        __builtin_amdgcn_sched_barrier(0);                          // the LDS reads are issued before the products, not after
+        products(cur_c);
+    };
+    if (kt0 < kt1) {
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+            if (kt0 + t < kt1) stage(t, kt0 + t);
+        wait_landed(min(NST - 1, kt1 - 1 - kt0));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(std::integral_constant<int, 0>{}, 0);
+        int st = 0;
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            const int s1 = st == NST - 1 ? 0 : st + 1, s2 = s1 == NST - 1 ? 0 : s1 + 1;
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, kt, st, s1);
+            if (kt + 1 < kt1) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, kt + 1, s1, s2);
+            st = s2;
+        }
     }
     const int nkt = (int)(g.c0 / BK);
     const int ktail = (int)(g.c0 - (int64_t)nkt * BK);             // columns behind the last full k-tile: c0 need not be aligned
@@ -228,9 +266,9 @@ __device__ __forceinline__ void tail_epilogue(const TailArgs<T>& g, int64_t m0, 
 }
 
 template <typename T, int NT, int JT>
-__global__ __launch_bounds__(256, JT == 2 ? 2 : 3) void tail_cols_kernel(TailArgs<T> g) {
+__global__ __launch_bounds__(256, tail_occ(NT, JT)) void tail_cols_kernel(TailArgs<T> g) {
     using acc_t = typename MF<T>::acc_t;
-    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * tail_stb(JT)];
+    __shared__ __attribute__((aligned(1024))) char smem[tail_nst(NT, JT) * tail_stb(NT, JT)];
     const int64_t m0 = (int64_t)blockIdx.x * (64 * JT);
     acc_t acc[4][2];
 #pragma unroll
@@ -251,9 +289,9 @@ __global__ __launch_bounds__(256, JT == 2 ? 2 : 3) void tail_cols_kernel(TailArg
 // by the host so that units / slots sits just below an integer.  Fixed assignment, fixed summation order in
 // tail_finish_kernel: the same bits in every run.
 template <typename T, int NT, int JT>
-__global__ __launch_bounds__(256, JT == 2 ? 2 : 3) void tail_part_kernel(TailArgs<T> g) {
+__global__ __launch_bounds__(256, tail_occ(NT, JT)) void tail_part_kernel(TailArgs<T> g) {
     using acc_t = typename MF<T>::acc_t;
-    __shared__ __attribute__((aligned(1024))) char smem[TAIL_NST * tail_stb(JT)];
+    __shared__ __attribute__((aligned(1024))) char smem[tail_nst(NT, JT) * tail_stb(NT, JT)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int nt = NT;
@@ -315,7 +353,8 @@ template <typename T, int JT>
 static int tail_dispatch(algp_ctx* c, TailArgs<T>& g, int64_t mpad, int nkt, int w) {
     // One workgroup per 64 JT rows leaves the last round of workgroups on a part of the machine (or, for a rank's share of
     // the candidates, never fills it): cut the k range so that the units fill the slots evenly ($ALGP_TAIL_SPLIT=0: never).
-    const int nrb = (int)(mpad / (64 * JT)), slots = JT == 2 ? 512 : 768;
+    const int nt = (w + 15) / 16;
+    const int nrb = (int)(mpad / (64 * JT)), slots = 256 * tail_occ(nt, JT);
     int best = 1;
     {
         static const bool split_on = !(getenv("ALGP_TAIL_SPLIT") && atoi(getenv("ALGP_TAIL_SPLIT")) == 0);
@@ -325,7 +364,6 @@ static int tail_dispatch(algp_ctx* c, TailArgs<T>& g, int64_t mpad, int nkt, int
         for (int s_ = 2; split_on && be < 0.94 && s_ <= 16 && nkt / s_ >= 48; ++s_)
             if (eff(s_) > be + 0.02) { be = eff(s_); best = s_; }
     }
-    const int nt = (w + 15) / 16;
     if (best == 1) {
         switch (nt) {
             case 1: hipLaunchKernelGGL((tail_cols_kernel<T, 1, JT>), dim3((unsigned)nrb), dim3(256), 0, c->cur, g); break;
@@ -384,7 +422,7 @@ int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
     g.part = nullptr;
     const int nkt = (int)(c0 / (16 / sizeof(T) * 8));
     ProfScope ps(c, klass, 2.0 * (double)mpad * (double)c0 * w, sizeof(T) * ((double)mpad * (double)c0 + 64.0 * (double)c0));
-    // $ALGP_TAIL_ROWS=64: 64 candidate rows per workgroup (48 KB of LDS: three workgroups per CU) instead of 128 (72 KB: two)
+    // $ALGP_TAIL_ROWS=64: 64 candidate rows per workgroup (three or four workgroups per CU) instead of 128 (two)
     static const bool rows64 = getenv("ALGP_TAIL_ROWS") && atoi(getenv("ALGP_TAIL_ROWS")) == 64;
     return rows64 ? tail_dispatch<T, 1>(c, g, mpad, nkt, w) : tail_dispatch<T, 2>(c, g, mpad, nkt, w);
 }
