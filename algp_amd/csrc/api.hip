@@ -1945,7 +1945,7 @@ struct Impl {
         // over the X the launch leaves -- no substitution chain runs beside S^-1 = X X^T any more (the two took 5.5 ms there,
         // starved by the GEMM).  $ALGP_FIT_ONE_LAUNCH=0: round 4's form.  (X X^T as tasks of the same launch as well was built
         // and measured in round 5 -- the launch grew by what the separate 5.1-ms GEMM launch costs, 12.9 -> 18.9 ms at N = 10 000
-        // fp64: the list leaves nothing idle to fill -- and removed again: DESIGN.md appendix.)
+        // fp64: the list leaves nothing idle to fill -- and removed again: EXPERIMENTS.md.)
         static const bool one_launch = !(getenv("ALGP_FIT_ONE_LAUNCH") && atoi(getenv("ALGP_FIT_ONE_LAUNCH")) == 0);
         const int64_t prow = (one_launch && grad_out) ? Npad + NB : Npad;
         if (c->N > 0 && panel_fits(Npad, prow)) {

@@ -518,7 +518,7 @@ def c5_rank_of_8(_hip, device, picks, steps=40, nranks=8, ranks=(0, 7), layout='
             tt = t[2:] if len(t) > 4 else t
             out['ranks'][str(st['r'])] = {'candidates': int(len(mine)), 'from_scratch_step_ms': per_rank[str(st['r'])][0],
                                           'ms_per_step_median': float(np.median(tt)), 'ms_per_step_p95': _pct(tt, 95),
-                                          'ms_per_step_max': float(np.max(tt)), 'step_ms_first_12': [round(v, 2) for v in t[:12]],
+                                          'ms_per_step_max': float(np.max(tt)), 'step_ms': [round(v, 2) for v in t],
                                           'row_exchanges': e.counter(3), 'fallbacks': e.counter(4),
                                           'staging_fills_inside_the_timed_step': st['refills'],
                                           'callbacks_agree_pick_rows': st['calls']}
