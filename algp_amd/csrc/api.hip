@@ -952,8 +952,11 @@ struct Impl {
             // noise changes); predictive semantics: it is an ordinary point at the same location
             ALGP_TRY(ensure(c, c->ckind, sizeof(int) * Mpad));
             ALGP_HIP(hipMemcpyAsync(c->ckind.p, kind.data(), sizeof(int) * Mpad, hipMemcpyHostToDevice, c->stream));
-            for (int64_t j : became_unit)
-                ALGP_HIP(hipMemsetAsync(p(c->Vt) + j * ldc, 0, sizeof(T) * keep, c->stream));
+            if (!became_unit.empty() && keep > 0) {                      // one launch for all of them
+                ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * became_unit.size()));
+                ALGP_HIP(hipMemcpyAsync(c->auxIdx.p, became_unit.data(), sizeof(int64_t) * became_unit.size(), hipMemcpyHostToDevice, c->stream));
+                ALGP_TRY(zero_listed_rows_launch<T>(c, p(c->Vt), ldc, (const int64_t*)c->auxIdx.p, (int64_t)became_unit.size(), keep));
+            }
             ALGP_TRY(sync(c));
         }
         KmatSrc s = make_src(c);

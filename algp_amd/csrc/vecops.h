@@ -20,6 +20,8 @@ int upper_gemv_launch(algp_ctx* c, const T* X, int64_t ld, int64_t n, const T* z
 template <typename T>
 int zero_rows3_launch(algp_ctx* c, T* acc3, int64_t stride, const int64_t* rows, int64_t n);
 template <typename T>
+int zero_listed_rows_launch(algp_ctx* c, T* X, int64_t ldx, const int64_t* rows, int64_t n, int64_t ncols);
+template <typename T>
 int rowstat_combine_launch(algp_ctx* c, const T* stat, int64_t ld, int ntiles, int64_t rows, T* ss, T* dot);
 template <typename T>
 int uw_init_launch(algp_ctx* c, T* u, T* w, const T* y, int64_t k, int64_t n, int64_t npad);

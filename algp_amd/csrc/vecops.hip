@@ -1106,6 +1106,24 @@ int zero_rows3_launch(algp_ctx* c, T* acc3, int64_t stride, const int64_t* rows,
 template int zero_rows3_launch<double>(algp_ctx*, double*, int64_t, const int64_t*, int64_t);
 template int zero_rows3_launch<float>(algp_ctx*, float*, int64_t, const int64_t*, int64_t);
 
+// X[rows[r]][0:ncols] = 0 for n listed rows (a workgroup per row and 2048 columns): the candidates that became train sites
+// in an incremental step restart as unit rows (one memset per row before: ~30 per step of config 5's loop, 0.2 ms in all).
+template <typename T>
+__global__ __launch_bounds__(256) void zero_listed_rows_kernel(T* X, int64_t ldx, const int64_t* rows, int64_t ncols) {
+    T* d = X + rows[blockIdx.x] * ldx;
+    const int64_t end = ncols < ((int64_t)blockIdx.y + 1) * 2048 ? ncols : ((int64_t)blockIdx.y + 1) * 2048;
+    for (int64_t k = (int64_t)blockIdx.y * 2048 + threadIdx.x; k < end; k += 256) d[k] = (T)0;
+}
+template <typename T>
+int zero_listed_rows_launch(algp_ctx* c, T* X, int64_t ldx, const int64_t* rows, int64_t n, int64_t ncols) {
+    if (n <= 0 || ncols <= 0) return ALGP_OK;
+    hipLaunchKernelGGL(zero_listed_rows_kernel<T>, dim3((unsigned)n, (unsigned)((ncols + 2047) / 2048)), dim3(256), 0, c->cur, X, ldx, rows, ncols);
+    ALGP_HIP(hipGetLastError());
+    return ALGP_OK;
+}
+template int zero_listed_rows_launch<double>(algp_ctx*, double*, int64_t, const int64_t*, int64_t, int64_t);
+template int zero_listed_rows_launch<float>(algp_ctx*, float*, int64_t, const int64_t*, int64_t, int64_t);
+
 // Fixed assignment and fixed summation order: the log-determinant of an updated factor is the same number in every run.
 // Workgroup b takes entries i = 256 (b + G q) + thread; its 4 wave sums go to part[4 b ..]; logdiag_sum_kernel adds the 4 G
 // partials in index order.  (One workgroup walked the 50 000 diagonal entries of config 5's factor -- one cache line each --
