@@ -339,9 +339,62 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const double* s, int64_t M
     }
 }
 
+// The same in two launches for long score vectors: ARGMAX_G workgroups leave their first maxima (value, index), one wave
+// folds them with the same rule -- which does not depend on how the entries were grouped.  (One workgroup walking config
+// 5's 100 000 utilities: 25-45 us, twice per pick.)
+constexpr int ARGMAX_G = 64;
+__global__ __launch_bounds__(256) void argmax_part_kernel(const double* s, int64_t M, double* pv, int64_t* pi) {
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
+    double bv = -INFINITY;
+    int64_t bi = -1;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < M; j += 256 * ARGMAX_G) {
+        const double v = s[j];
+        if (bi < 0 || v > bv) {     // j ascending per thread: strict > keeps the first maximum
+            if (!(v != v)) { bv = v; bi = j; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(bv, o, 64);
+        const int64_t oi = __shfl_down(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] < bi))) { bv = sv[w]; bi = si[w]; }
+        pv[blockIdx.x] = bv;
+        pi[blockIdx.x] = bi;
+    }
+}
+__global__ __launch_bounds__(64) void argmax_final_kernel(const double* pv, const int64_t* pi, double* out_val, int64_t* out_idx) {
+    double bv = pv[threadIdx.x];
+    int64_t bi = pi[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(bv, o, 64);
+        const int64_t oi = __shfl_down(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    if (threadIdx.x == 0) {
+        *out_val = bv;
+        *out_idx = bi;
+    }
+}
+
 int argmax_launch(algp_ctx* c, const double* s, int64_t M, double* out_val, int64_t* out_idx) {
     ProfScope ps(c, ALGP_PROF_SCORE, (double)M, 8.0 * M);
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->cur, s, M, out_val, out_idx);
+    static_assert(ARGMAX_G == 64, "argmax_final_kernel folds the partial maxima with one wave");
+    if (M >= 32768) {
+        ALGP_TRY(ensure(c, c->amax, 16 * ARGMAX_G));
+        double* pv = (double*)c->amax.p;
+        int64_t* pi = (int64_t*)(pv + ARGMAX_G);
+        hipLaunchKernelGGL(argmax_part_kernel, dim3(ARGMAX_G), dim3(256), 0, c->cur, s, M, pv, pi);
+        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(64), 0, c->cur, (const double*)pv, (const int64_t*)pi, out_val, out_idx);
+    } else {
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->cur, s, M, out_val, out_idx);
+    }
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }

@@ -205,6 +205,43 @@ def test_fit_and_solve_equals_separate_calls(dtname):
     c.close()
 
 
+def test_argmax_over_a_long_score_vector_is_the_first_maximum():
+    """np.argmax semantics (agent.py:349) for score vectors of 32 768 entries and more, which algp_argmax and the lazy pick
+    chain reduce in two launches (64 workgroups' first maxima, then one wave): every site listed three times as a candidate,
+    so the maximum is attained three times -- the first position must win, whatever workgroup holds it; then the chain
+    algp_greedy runs (argmax -> refresh -> refresh -> argmax on the device) against pick-by-pick scoring on the host."""
+    c = _hip.Context(np.float64)
+    rng = np.random.RandomState(11)
+    n, ntr = 14000, 300
+    X = rng.uniform(0, 120, (n, 2))
+    c.set_hypers(np.log([3.0, 2.5]), 0.0, np.log(1e-2))
+    c.set_pool(X)
+    A = rng.permutation(n)[:ntr]
+    c.set_train(A, np.zeros(ntr), np.full(ntr, 0.01))
+    c.factorize()
+    base = np.setdiff1d(np.arange(n), A)
+    cand = np.r_[base, base, base]                              # 41 100 candidates, every utility three times
+    assert len(cand) >= 32768
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    for _ in range(3):
+        s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        want = int(np.argmax(s))
+        assert want < len(base) and s[want] == s[want + len(base)] == s[want + 2 * len(base)]
+        pos, pool, val = c.argmax()
+        assert (pos, pool, val) == (want, int(cand[want]), s[want])
+        c.commit_pick(pool, 0.1, 1.0)
+    c.factorize()
+    c.solve_candidates()
+    picks = [int(p) for p in c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)]
+    c.solve_candidates()
+    for q in range(3):
+        s = c.scores(_hip.CRIT_ENTROPY, 0.1, 1.0)
+        assert picks[q] == int(cand[int(np.argmax(s))])
+        c.commit_pick(picks[q], 0.1, 1.0)
+    c.close()
+
+
 @pytest.mark.parametrize('mode', ['coords', 'cov'])
 @pytest.mark.parametrize('dtname', ['f64', 'f32'])
 def test_lazy_greedy_equals_full_pass(dtname, mode):
