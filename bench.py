@@ -889,6 +889,7 @@ def main():
     ap.add_argument('--loop', type=int, default=0, help='K > 0: run config 5\'s active-learning loop for K incremental steps on the --gpus ranks '
                     'instead of the config-4 step (candidates sharded, factor replicated; see loop_mode)')
     ap.add_argument('--loop-field', type=lambda v: tuple(int(x) for x in v.split('x')), default=(250, 200), help='RxC of the loop\'s field (default 250x200 = 50 000 sites)')
+    ap.add_argument('--extra-loop-timeout', type=int, default=300, help='seconds after which the N > 1 extra leg is abandoned (the line is printed without it)')
     ap.add_argument('--extra-loop-steps', type=int, default=200, help='with --gpus N > 1 the line also carries extra.c5_loop: config 5\'s loop '
                     'for this many incremental steps on the N ranks (0 or --no-extras: skipped)')
     ap.add_argument('--cpu-train', type=int, default=6000)
@@ -1067,21 +1068,6 @@ def main():
     if rank == 0 and world == 1 and want != 'weak' and not args.no_emulation:
         emu = strong_emulation(ctx, _hip, res, args)
 
-    # N > 1: BASELINE config 5 in its stated form as well -- the active-learning loop on the N ranks (every rank takes part)
-    c5_multi = None
-    if world > 1 and not args.no_extras and args.extra_loop_steps > 0:
-        ctx.close()
-        ctx = None
-        largs = argparse.Namespace(**vars(args))
-        largs.loop, largs.cand = args.extra_loop_steps, 100000 if args.cand == 100000 or want == 'weak' else args.cand
-        t0 = time.perf_counter()
-        try:
-            c5_multi = loop_mode(largs, world, rank, local_rank, dist, torch)
-        except Exception as e:                                   # must not cost the headline line (every rank raises alike or none)
-            c5_multi = {'error': '%s: %s' % (type(e).__name__, e)}
-        if c5_multi is not None:
-            c5_multi['leg_wall_s'] = time.perf_counter() - t0
-
     if rank == 0:
         K = args.steps
         w, N, total_c, prof, chol_stats = res['w'], res['N'], res['total_c'], res['prof'], res['chol_stats']
@@ -1199,7 +1185,7 @@ def main():
                                'each winner).  ms_per_step = the slower of the two ranks; speedup_vs_1 = this run\'s ms_per_step / that; '
                                'scoring_only_* subtract the replicated fit timed on its own (fit_alone_ms) from the rank\'s step and '
                                'stage_ms_per_step.cholesky from the one-GPU step.  Not in it: RCCL\'s wire time for n x 80 KB per pick (the '
-                               'host transport\'s two synchronisations, PCIe staging copies and a raw Python callback are in it instead) and skew between '
+                               'host transport\'s synchronisation, its PCIe staging copies and a raw Python callback are in it instead) and skew between '
                                'ranks.  Up to 51 200 rows the fit and the solve are ONE task-list launch (fit_and_solve_in_one_launch).')
                 out['strong_emulation'] = emu
         if weak is not None:
@@ -1208,6 +1194,43 @@ def main():
                                    'ms_per_step_unprofiled': 1e3 * weak['elapsed_unprof'] / K,
                                    'candidates_per_gpu': weak['M0'], 'candidates_total': weak['total_c'],
                                    'picks_last_step': weak['picks']}
+
+    # N > 1: BASELINE config 5 in its stated form as well -- the active-learning loop on the N ranks (every rank takes part).
+    # The headline line is complete at this point and must not be lost to this leg: every rank runs it under a watchdog that,
+    # when no result has come after --extra-loop-timeout seconds (a rank stuck in a collective), lets rank 0 print the line
+    # with the failure noted and ends the process (each rank its own: all of them leave).
+    c5_multi = None
+    if world > 1 and not args.no_extras and args.extra_loop_steps > 0:
+        import threading
+        if ctx is not None:
+            ctx.close()
+            ctx = None
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(args.extra_loop_timeout):
+                return
+            if rank == 0:
+                out['extra'] = {'c5_loop': {'error': 'no result after %d s: abandoned so that the headline line is not lost' % args.extra_loop_timeout}}
+                out['cpu_baseline'] = None
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                print(json.dumps(out))
+                sys.stdout.flush()
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        largs = argparse.Namespace(**vars(args))
+        largs.loop, largs.cand = args.extra_loop_steps, 100000 if args.cand == 100000 or want == 'weak' else args.cand
+        t0 = time.perf_counter()
+        try:
+            c5_multi = loop_mode(largs, world, rank, local_rank, dist, torch)
+        except Exception as e:                                   # must not cost the headline line (every rank raises alike or none)
+            c5_multi = {'error': '%s: %s' % (type(e).__name__, e)}
+        done.set()
+        if c5_multi is not None:
+            c5_multi['leg_wall_s'] = time.perf_counter() - t0
+
+    if rank == 0:
         extras = {}
         if world == 1 and not args.no_extras:
             ctx.close()

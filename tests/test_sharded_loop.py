@@ -249,3 +249,15 @@ def test_bench_multi_rank_line_carries_the_loop_as_an_extra():
     assert 'error' not in lp, lp
     assert lp['n_gpus'] == 2 and lp['steps'] == 4 and lp['row_exchanges'] == 4 and lp['fallbacks_to_the_triangular_solve'] == 0
     assert lp['config']['candidates_per_gpu'] == 4500 and lp['value'] > 0
+
+
+def test_bench_multi_rank_line_survives_a_stuck_extra_leg():
+    """The N > 1 extra leg runs under a watchdog on every rank: with a limit the leg cannot meet (0 s) the headline line is
+    still printed -- by rank 0, with the failure noted under extra.c5_loop -- and every rank ends with status 0, as it must
+    if a rank were stuck in a collective of that leg on a real node."""
+    two = _bench(['--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '1', '--train', '2500', '--cand', '9000',
+                  '--loop-field', '60x50', '--extra-loop-steps', '50', '--extra-loop-timeout', '0', '--no-cpu-baseline'],
+                 {'ALGP_BENCH_DEVICE': '0'})
+    assert two['n_gpus'] == 2 and two['config']['candidates_total'] == 9000 and two['value'] > 0
+    assert 'abandoned' in two['extra']['c5_loop']['error']
+
