@@ -253,7 +253,9 @@ int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen
  *   per rank, cap = the largest number of new sites any rank owns (every rank derives the same plan from the train set
  *   and the map).  A rank whose V^T cannot supply its rows (no resident solve for these hyper-parameters / this
  *   candidate list) says so in the agreement and EVERY rank falls back to the solve; an error (allocation, injected) is
- *   returned by every rank, the second collective is then not entered by anyone.  With any map other than contiguous
+ *   returned by every rank, the second collective is then not entered by anyone.  (What is left: a HIP failure of the
+ *   pack launch or its copies BETWEEN the two collectives returns from that rank alone -- the buffers are reserved before
+ *   the agreement, so this means a lost device, not a full one.)  With any map other than contiguous
  *   shards in rank order the pick's first maximum still equals np.argmax in pool order: equal utilities go to the smaller
  *   pool index.  The calls that follow -- algp_solve_candidates_update on the rank's shard, algp_greedy_sharded -- are
  *   unchanged.  algp_debug_counter(ctx, 1..4): rows of L the last factor update placed without a triangular solve, how many
