@@ -109,7 +109,8 @@ __device__ __forceinline__ void tile_mainloop(char* smem, const T* A0, int64_t l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int srow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((lane >> 4) & 3);
+    // chunk XOR ((row >> 2) & 2): conflict-free for the four 16-lane groups a ds_read_b128 is served in (gemm.hip)
+    const int schunk = (lane & 3) ^ ((lane >> 4) & 2);
     const T* Ag = A0 + (int64_t)(32 * wave + srow) * lda + schunk * EPC;
     const T* Bg = B0 + (int64_t)(32 * wave + srow) * ldb + schunk * EPC;
     auto stage = [&](int st, int kt) {
@@ -124,7 +125,7 @@ __device__ __forceinline__ void tile_mainloop(char* smem, const T* A0, int64_t l
         }
     };
     const int fr = lane & 15, fg = lane >> 4;
-    const int coff = ((fg ^ ((fr >> 2) & 3)) << 4);
+    const int coff = ((fg ^ ((fr >> 2) & 2)) << 4);
     const int aoff = (wr * 64 + fr) * 64 + coff;
     const int boff = (wc * 64 + fr) * 64 + coff;
 #pragma unroll
@@ -341,9 +342,9 @@ __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int srow = lane >> 2;
-    const int bchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const int bchunk = (lane & 3) ^ ((lane >> 4) & 2);
     const int arow = SR == 32 ? 8 * wave + (srow & 7) : srow;
-    const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
+    const int achunk = (lane & 3) ^ ((arow >> 2) & 2);
     const T* Ag = A0 + (int64_t)arow * lda + achunk * EPC;
     const T* Bg = B0 + (int64_t)(32 * wave + srow) * ldb + bchunk * EPC;
     const bool stages_a = SR == 32 || wave == 0;                   // wave-uniform
@@ -357,7 +358,7 @@ __device__ __forceinline__ void strip_mainloop(char* smem, const T* A0, int64_t 
                                              (lds_vp)(Bs + i * 1024), 16, 0, 0);
     };
     const int fr = lane & 15, fg = lane >> 4;
-    const int coff = ((fg ^ ((fr >> 2) & 3)) << 4);
+    const int coff = ((fg ^ ((fr >> 2) & 2)) << 4);
     // 32 rows: A row 16 i + fr sits in the 1 KB of wave (2 i + (fr >> 3)), local row fr & 7; 16 rows: row fr of the one KB
     const int aoff = SR == 32 ? (fr >> 3) * 1024 + (fr & 7) * 64 + coff : fr * 64 + coff;
     const int boff = 4096 + (32 * wave + fr) * 64 + coff;
