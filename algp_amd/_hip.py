@@ -444,6 +444,7 @@ class Context(object):
     def comm_destroy(self):
         self._check(self.lib.algp_comm_destroy(self.h))
         self._gather_cb = None
+        self._shard_link = None
 
     def comm_set_owners(self, owner):
         """owner[q] = rank that holds pool site q as a candidate (-1: nobody), the same array on every rank; None clears

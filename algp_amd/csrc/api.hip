@@ -473,17 +473,21 @@ struct Impl {
     // solve them against the kept factor instead (some rank's V^T cannot supply its rows).  An error code >= 2 of any
     // rank (an allocation that failed, ...) is returned by every rank.  Reference: agent.py:66-82 (the sites a step adds),
     // agent.py:313-354 (the loop whose shards own them).
-    static int exchange_new_rows(algp_ctx* c, int64_t Nb, int64_t p0, int* placed) {
+    // st_in: what this rank found BEFORE the plan (0; 1 = it keeps nothing of its factor, Nb = 0; >= 2 = an allocation of
+    // the factor itself failed): it travels in the agreement word like every later failure, so that no rank returns
+    // from factorize_update before the agreement its peers are waiting in.
+    static int exchange_new_rows(algp_ctx* c, int64_t Nb, int64_t p0, int* placed, int st_in = 0) {
         const int64_t N = c->N, Npad = c->Npad, ld = c->Lld;
         const int nr = c->comm_nranks, me = c->comm_rank;
         const int64_t nnew = N - p0, ntot = Npad - p0;
         *placed = 0;
         std::vector<int> owner((size_t)std::max<int64_t>(nnew, 0)), slot((size_t)std::max<int64_t>(nnew, 0));
         std::vector<int64_t> cnt((size_t)nr, 0);
-        int st = 0;
+        int st = st_in;
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
         mix((uint64_t)Nb);
+        mix(c->site_owner_hash);                                             // the WHOLE owner map, not only the new sites' entries
         for (int64_t i = 0; i < nnew; ++i) {
             const int64_t q = c->train_idx[(size_t)(p0 + i)];
             const int o = c->site_owner[(size_t)q];
@@ -499,7 +503,7 @@ struct Impl {
         std::vector<int64_t> src_row((size_t)std::max<int64_t>(cap, 1), -1), lrow((size_t)std::max<int64_t>(cap, 1), -1);
         std::vector<T> lscale((size_t)std::max<int64_t>(cap, 1), (T)0);
         bool second = false;
-        if (st == 0 && cnt[(size_t)me] > 0) {
+        if (st == 0 && Nb > 0 && cnt[(size_t)me] > 0) {
             bool ok = c->Vt.p && c->vt_hyp_stamp == c->hyp_stamp && (int64_t)c->vt_fact_idx.size() >= Nb &&
                       c->vt_cand_idx == c->cand_idx && (int64_t)c->vt_kind.size() == c->M;
             for (int64_t r = 0; ok && r < Nb; ++r)
@@ -555,8 +559,12 @@ struct Impl {
                                       " before the row exchange; no rank updated its factor");
         }
         if (worst == 1 || !same) {
-            c->row_fallbacks += 1;
-            return ALGP_OK;                                                  // every rank solves the rows itself
+            // every rank builds the rows itself: the solve against its kept blocks, or (a rank that keeps nothing) from scratch.
+            // Not a fall-back when NO rank keeps anything: then there was nothing to exchange (the first factorisation of a run).
+            bool any_kept = false;
+            for (int r = 0; r < nr; ++r) any_kept = any_kept || all[(size_t)r * 4 + 1] >= (double)NB;
+            if (any_kept) c->row_fallbacks += 1;
+            return ALGP_OK;
         }
         if (cap > 0) {
             T* own = (T*)c->rowx.p;
@@ -606,10 +614,21 @@ struct Impl {
         }
         c->factored = false;
         c->solved = false;
-        ALGP_TRY(reserve_factor(c, Npad, keep, p0, incremental != 0));
+        // candidates sharded over ranks (a transport and an owner map of this pool attached): the incremental call is a
+        // COLLECTIVE whatever this rank finds locally -- a rank that keeps nothing (an earlier factorisation failed, other
+        // hyper-parameters) or whose factor cannot be re-allocated says so in the agreement its peers enter
+        const bool sharded = incremental && (c->comm || c->host_gather) && c->comm_nranks > 1 && !c->site_owner.empty() &&
+                             (int64_t)c->site_owner.size() == c->n_pool;
+        int pre = reserve_factor(c, Npad, keep, p0, incremental != 0);
+        if (pre == ALGP_OK) pre = ensure(c, c->z, sizeof(T) * Npad);
+        if (pre == ALGP_OK) pre = ensure(c, c->alpha, sizeof(T) * Npad);
+        if (sharded && (pre != ALGP_OK || keep == 0)) {
+            int placed_unused = 0;
+            const int arc = exchange_new_rows(c, 0, p0, &placed_unused, pre != ALGP_OK ? pre : 1);
+            if (arc != ALGP_OK) return arc;                                  // this rank's failure, or a peer's: the same code everywhere
+        }
+        ALGP_TRY(pre);
         const int64_t ld = c->Lld;
-        ALGP_TRY(ensure(c, c->z, sizeof(T) * Npad));
-        ALGP_TRY(ensure(c, c->alpha, sizeof(T) * Npad));
         KmatSrc s = make_src(c);
         double ld_total = 0;
         prof_span_begin(c, ALGP_PROF_CHOLESKY, keep == 0 ? (double)N * N * N / 3.0 : (double)(N - keep) * N * N,
@@ -631,9 +650,7 @@ struct Impl {
             std::vector<int64_t> src_row, lrow;
             std::vector<T> lscale;
             bool second = false;
-            // candidates sharded over ranks: the rows come from their owners (one exchange); this call is then a COLLECTIVE
-            const bool sharded = (c->comm || c->host_gather) && c->comm_nranks > 1 && !c->site_owner.empty() &&
-                                 (int64_t)c->site_owner.size() == c->n_pool;
+            // candidates sharded over ranks: the rows come from their owners (one exchange)
             int placed = 0;
             c->rows_from_peers = 0;
             if (sharded) {
@@ -2116,6 +2133,8 @@ int algp_set_pool(algp_ctx* c, const void* x, int64_t n) {
     c->hyp_stamp++;
     c->pos_in_train.clear();
     c->N = 0;
+    c->site_owner.clear();                                   // the owner map belongs to the pool it was given for (re-attach it: algp_comm_set_owners)
+    c->site_owner_hash = 0;
     FINISH(c, DISPATCH(c, set_pool(c, x, n)));
 }
 
@@ -2127,6 +2146,8 @@ int algp_set_pool_cov(algp_ctx* c, const void* cov, int64_t n) {
     c->hyp_stamp++;
     c->pos_in_train.clear();
     c->N = 0;
+    c->site_owner.clear();                                   // the owner map belongs to the pool it was given for (re-attach it: algp_comm_set_owners)
+    c->site_owner_hash = 0;
     FINISH(c, DISPATCH(c, set_pool_cov(c, cov, n)));
 }
 
@@ -2321,12 +2342,15 @@ int64_t algp_debug_counter(algp_ctx* c, int which) {
 }
 int algp_comm_set_owners(algp_ctx* c, const int32_t* owner, int64_t n_pool) {
     CHECK_CTX(c);
-    if (!owner) { c->site_owner.clear(); return ALGP_OK; }
+    if (!owner) { c->site_owner.clear(); c->site_owner_hash = 0; return ALGP_OK; }
     if (!c->comm && !c->host_gather) return fail(c, ALGP_ERR_STATE, "comm_set_owners: call algp_comm_init (or algp_comm_init_host) first");
     if (n_pool != c->n_pool || n_pool <= 0) return fail(c, ALGP_ERR_BAD_ARG, "comm_set_owners: one entry per pool site (set the pool first)");
     for (int64_t i = 0; i < n_pool; ++i)
         if (owner[i] < -1 || owner[i] >= c->comm_nranks) return fail(c, ALGP_ERR_BAD_ARG, "comm_set_owners: rank outside the communicator");
     c->site_owner.assign(owner, owner + n_pool);
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t i = 0; i < n_pool; ++i) h = (h ^ (uint64_t)(int64_t)owner[i]) * 1099511628211ull;
+    c->site_owner_hash = h;
     return ALGP_OK;
 }
 int algp_debug_set_trsm_chunks(algp_ctx* c, int chunks) {

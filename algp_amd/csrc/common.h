@@ -216,6 +216,7 @@ struct algp_ctx {
     // the factor update's row exchange (comm.hip, api.hip: exchange_new_rows): which rank holds each pool site as a candidate
     // (algp_comm_set_owners; empty: no exchange), [own rows | gathered rows] on the device, pinned staging (host transport)
     std::vector<int32_t> site_owner;
+    uint64_t site_owner_hash = 0;                              // FNV-1a of the whole map: part of the agreement word of a sharded factor update
     algp::DevBuf rowx;
     void* rowx_host = nullptr;
     size_t rowx_host_cap = 0;

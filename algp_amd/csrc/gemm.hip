@@ -96,6 +96,12 @@ __device__ __forceinline__ T row16_sum(T x) {
 // conflict cycles (2.4e10 of 4.8e10 in the bench run) -- at no measurable cost in time (164.8-165.2 vs 165.2 ms per step, A/B on
 // one box): the LDS array is busy for a tenth of the kernel either way.
 // ---------------------------------------------------------------------------------------------
+// (-DALGP_GEMM_XOR_MASK=3 builds the image of rounds 1-4, for the traffic A/B of round 6: tools/xor_traffic_ab.sh measured
+// 0.93 GB of fabric reads per launch with it against 1.16 GB with this one at the same request count -- 18 % fewer L2
+// misses -- and the same time; profiles/r06_xor_traffic_ab.txt)
+#ifndef ALGP_GEMM_XOR_MASK
+#define ALGP_GEMM_XOR_MASK 2
+#endif
 template <typename T, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
     constexpr int NST = 4;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
     // ---- DMA: wave w stages rows [32w, 32w+32) of each operand as two 16-row groups; lane l -> row l>>2 of
     // the group, LDS slot l&3, which must hold chunk (l&3) ^ ((row>>2)&2) = (l&3) ^ ((l>>4)&2)
     const int srow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((lane >> 4) & 2);
+    const int schunk = (lane & 3) ^ ((lane >> 4) & ALGP_GEMM_XOR_MASK);
     const T* Ag = g.A + bz * g.sA + (m0 + 32 * wave + srow) * g.lda + schunk * EPC + (int64_t)kskip * BK;
     const T* Bg = g.B + bz * g.sB + (n0 + 32 * wave + srow) * g.ldb + schunk * EPC + (int64_t)kskip * BK;
     auto stage = [&](int st, int kt) {
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel_dma4(GemmArgs<T> g) {
 
     // ---- fragment reads: row = w*64 + t*16 + (lane&15), chunk (lane>>4) ^ ((row>>2)&2) ----
     const int fr = lane & 15, fg = lane >> 4;
-    const int coff = ((fg ^ ((fr >> 2) & 2)) << 4);                // (row>>2)&2 == (fr>>2)&2: the row offsets are multiples of 16
+    const int coff = ((fg ^ ((fr >> 2) & ALGP_GEMM_XOR_MASK)) << 4);   // (row>>2)&2 == (fr>>2)&2: the row offsets are multiples of 16
     const int aoff = (wr * 64 + fr) * 64 + coff;
     const int boff = (wc * 64 + fr) * 64 + coff;
 

@@ -58,6 +58,7 @@ class ShardLink(object):
             raise ValueError("layout must be 'strided' or 'contiguous'")
         self.rank, self.world_size = int(rank), int(world_size)
         self.unique_id, self.all_gather, self.layout = unique_id, all_gather, layout
+        self._id_used = False
 
     def owners(self, n_pool):
         if self.layout == 'strided':
@@ -72,11 +73,23 @@ class ShardLink(object):
         return np.nonzero(self.owners(n_pool) == self.rank)[0].astype(np.int64)
 
     def attach(self, ctx, n_pool):
-        """Join `ctx` (its pool already set) to the job: transport, then the owner map."""
-        if self.unique_id is not None:
-            ctx.comm_init(self.world_size, self.rank, self.unique_id)
-        else:
-            ctx.comm_init_host(self.world_size, self.rank, self.all_gather)
+        """Join `ctx` (its pool already set) to the job: the transport ONCE per context, then the owner map.
+
+        A context keeps its communicator across pool reloads (algp_set_pool drops only the owner map), and an RCCL
+        unique id is single-use -- the root's bootstrap listener is gone after the first ncclCommInitRank -- so a second
+        attach of the same context (the Agent reloads its pool whenever the hyper-parameters change or another caller
+        has loaded one in between) must only re-send the map.  A context that needs a NEW communicator needs a new
+        ShardLink with a fresh id from rank 0."""
+        if getattr(ctx, '_shard_link', None) is not self:
+            if self.unique_id is not None:
+                if self._id_used:
+                    raise RuntimeError('ShardLink: this RCCL unique id has already initialised a communicator; '
+                                       'create a new ShardLink with a fresh id (rank 0: Context.comm_unique_id())')
+                ctx.comm_init(self.world_size, self.rank, self.unique_id)
+                self._id_used = True
+            else:
+                ctx.comm_init_host(self.world_size, self.rank, self.all_gather)
+            ctx._shard_link = self
         ctx.comm_set_owners(self.owners(n_pool))
 
 

@@ -38,6 +38,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+WATCHDOG_EXIT = 3                   # status of every rank when the N > 1 extra leg is abandoned by its watchdog
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix (= vector) peak, SURVEY.md section 8(d)
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip-level parameters
 HBM_PEAK_GBS = 8000.0
@@ -743,7 +744,7 @@ def strong_emulation(ctx, _hip, res, args):
     return out
 
 
-def loop_mode(args, world, rank, local_rank, dist, torch):
+def loop_mode(args, world, rank, local_rank, dist, torch, progress=None):
     """`bench.py --loop K [--gpus N]`: BASELINE config 5's active-learning loop itself (reference agent.py:125-229) on N real
     ranks -- every rank replicates the factor of the growing train set and owns 1/N of the candidates (sharded.ShardLink,
     strided owner map); per planning step: factor update with the new train sites' rows arriving in the row exchange
@@ -786,9 +787,14 @@ def loop_mode(args, world, rank, local_rank, dist, torch):
     static[:N0] = var == 0.01
     cidx = np.arange(N0, n)
 
+    def note(where):
+        if progress is not None:
+            progress['where'] = where
+
     def barrier():
         ctx.sync()
         if dist is not None:
+            note('barrier between steps')
             dist.barrier()
     times, picks_log = [], []
     t_all = None
@@ -799,9 +805,12 @@ def loop_mode(args, world, rank, local_rank, dist, torch):
         barrier()
         t0 = time.perf_counter()
         ctx.set_train(idx, y, var)
+        note('step %d of %d: factorize(incremental) -- agreement word + row all-gather' % (s, args.loop))
         ctx.factorize(incremental=True)
         ctx.set_candidates(mine, prior_includes_noise=True)
+        note('step %d of %d: solve_candidates (rank-local)' % (s, args.loop))
         ctx.solve_candidates(incremental=True, alive=~static[mine])
+        note('step %d of %d: greedy -- one all-gather per pick' % (s, args.loop))
         if world > 1:
             pk = [int(p) for p in ctx.greedy_sharded(_hip.CRIT_ENTROPY, 0.1, 1.0, args.picks)]
         else:
@@ -1206,26 +1215,37 @@ def main():
             ctx.close()
             ctx = None
         done = threading.Event()
+        line_lock = threading.Lock()                               # exactly one of {watchdog, main thread} prints the line
+        progress = {'where': 'starting'}                          # what the loop was doing when the watchdog fired (loop_mode updates it)
 
         def watchdog():
             if done.wait(args.extra_loop_timeout):
                 return
+            if not line_lock.acquire(blocking=False):              # the main thread is printing already: let it finish
+                return
+            print('bench: rank %d: extra loop leg gave no result after %d s (%s); leaving with status %d'
+                  % (rank, args.extra_loop_timeout, progress['where'], WATCHDOG_EXIT), file=sys.stderr)
             if rank == 0:
-                out['extra'] = {'c5_loop': {'error': 'no result after %d s: abandoned so that the headline line is not lost' % args.extra_loop_timeout}}
+                out['extra'] = {'c5_loop': {'error': 'no result after %d s: abandoned so that the headline line is not lost; rank 0 was at: %s; '
+                                                     'every rank exits with status %d' % (args.extra_loop_timeout, progress['where'], WATCHDOG_EXIT)}}
                 out['cpu_baseline'] = None
                 sys.stdout.flush()
                 os.dup2(saved_stdout, 1)
                 print(json.dumps(out))
                 sys.stdout.flush()
-            os._exit(0)
+            # a process that has touched the GPU and is abandoned mid-collective did NOT succeed: non-zero on every
+            # rank; self_spawn relays the line and this code
+            os._exit(WATCHDOG_EXIT)
         threading.Thread(target=watchdog, daemon=True).start()
         largs = argparse.Namespace(**vars(args))
         largs.loop, largs.cand = args.extra_loop_steps, 100000 if args.cand == 100000 or want == 'weak' else args.cand
         t0 = time.perf_counter()
         try:
-            c5_multi = loop_mode(largs, world, rank, local_rank, dist, torch)
+            c5_multi = loop_mode(largs, world, rank, local_rank, dist, torch, progress=progress)
         except Exception as e:                                   # must not cost the headline line (every rank raises alike or none)
             c5_multi = {'error': '%s: %s' % (type(e).__name__, e)}
+        if not line_lock.acquire(blocking=False):                  # the watchdog fired first and is printing: it ends the process
+            time.sleep(3600)
         done.set()
         if c5_multi is not None:
             c5_multi['leg_wall_s'] = time.perf_counter() - t0

@@ -15,6 +15,13 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <mutex>
+#include <set>
+#include <string>
+
+static std::mutex g_ids_mu;
+static std::set<std::string> g_ids_used;                        // "<id>#<rank>" joined by this process (ranks may be threads of one process)
+
 extern "C" {
 
 typedef struct { char internal[128]; } ncclUniqueId;
@@ -26,8 +33,8 @@ typedef FakeComm* ncclComm_t;
 constexpr int MAX_RANKS = 16;
 constexpr size_t SLOT = 4 << 20;                               // per rank: a pick's payload, or a factor update's rows (cap rows of the kept width)
 struct Shared {
-    int count, gen, calls;
-    char pad[52];
+    int count, gen, calls, used;                                // used: every rank has joined once -- a second join with this id is refused
+    char pad[48];
     char slots[MAX_RANKS][SLOT];
 };
 struct FakeComm {
@@ -65,6 +72,13 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
 
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
     if (nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks || id.internal[0] != '/') return 4;   // ncclInvalidArgument
+    // a real ncclUniqueId is SINGLE-USE (the root's bootstrap listener is gone after the first init): refuse a second join
+    // of this process with the same id, and a join of a segment every rank has already joined once
+    {
+        std::lock_guard<std::mutex> lk(g_ids_mu);
+        const std::string key = std::string(id.internal) + "#" + std::to_string(rank);
+        if (!g_ids_used.insert(key).second) return 3;
+    }
     const int fd = shm_open(id.internal, O_CREAT | O_RDWR, 0600);
     if (fd < 0) return 2;                                       // ncclSystemError
     if (ftruncate(fd, sizeof(Shared)) != 0) { close(fd); return 2; }
@@ -77,7 +91,10 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     c->rank = rank;
     strncpy(c->name, id.internal, sizeof(c->name) - 1);
     c->name[sizeof(c->name) - 1] = 0;
+    if (__atomic_load_n(&c->sh->used, __ATOMIC_ACQUIRE)) { munmap(p, sizeof(Shared)); delete c; return 3; }
     if (!barrier(c)) return 3;                                  // ncclInternalError: a rank never arrived
+    if (!barrier(c)) return 3;                                  // (everybody has checked `used` before anybody sets it)
+    __atomic_store_n(&c->sh->used, 1, __ATOMIC_RELEASE);
     *comm = c;
     return 0;
 }
@@ -107,7 +124,7 @@ const char* ncclGetErrorString(ncclResult_t r) {
         case 0: return "no error";
         case 1: return "unhandled HIP error (test double)";
         case 2: return "system error (test double: shared memory)";
-        case 3: return "internal error (test double: a rank did not reach the barrier within 60 s)";
+        case 3: return "internal error (test double: a rank did not reach the barrier within 60 s, or a unique id was used twice)";
         case 4: return "invalid argument (test double)";
     }
     return "unknown";

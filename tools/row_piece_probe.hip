@@ -69,6 +69,58 @@ static void run(const double* X, int64_t rows, int64_t ldx, int64_t ncols, doubl
     fflush(stdout);
 }
 
+
+// The GEMM's own request pattern (gemm.hip: stage()): P-byte row pieces by LDS-DMA, 16 bytes per lane, the P / 16 lanes of a
+// piece in the order `lane ^ x` -- XORM 0: x = 0; 1: x = (row >> 2) & 3 (rounds 1-4); 2: x = (row >> 2) & 2 (round 5) -- U
+// k-steps in flight per wave.  The bytes are only counted, never read back: for the FETCH_SIZE calibration
+// (tools/fetch_calibrate.sh), where every launch moves a known number of bytes.
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+template <int P, int XORM, int U>
+__global__ __launch_bounds__(256) void probe_dma(const double* X, int64_t ldx, int64_t ncols, double* out) {
+    extern __shared__ char smem[];
+    constexpr int LPR = P / 16, RPW = 64 / LPR, NP = 128 / (4 * RPW), EP = P / 8;   // rows per wave and instruction; instructions per k-step
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    const int row = lane / LPR;
+    const int x = XORM == 1 ? ((row >> 2) & 3) : XORM == 2 ? ((row >> 2) & 2) : 0;
+    const int chunk = ((lane % LPR) ^ x) % LPR;
+    const double* base = X + (m0 + wave * (128 / 4) + row) * ldx + chunk * 2;
+    const int64_t nk = ncols / EP;
+    for (int64_t k = 0; k < nk; ++k) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            __builtin_amdgcn_global_load_lds((glb_vp)(base + (int64_t)p * RPW * ldx + k * EP),
+                                             (lds_vp)(smem + ((((k % U) * NP + p) & 15) * 4096) + wave * 1024), 16, 0, 0);
+        if (NP * (U - 1) >= 8) __builtin_amdgcn_s_waitcnt(0x0F78);
+        else if (NP * (U - 1) >= 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+        else __builtin_amdgcn_s_waitcnt(0x0F72);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (ncols < 0) out[blockIdx.x] = (double)smem[t];
+}
+template <int P, int XORM, int U>
+static void run_dma(const double* X, int64_t rows, int64_t ldx, int64_t ncols, double* out, int lds_kb, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute((const void*)probe_dma<P, XORM, U>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
+    float best = 1e30f;
+    for (int it = 0; it < reps; ++it) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((probe_dma<P, XORM, U>), dim3((unsigned)(rows / 128)), dim3(256), lds_kb * 1024, 0, X, ldx, ncols, out);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double bytes = (double)rows * (double)(ncols / (P / 8)) * P;
+    printf("LDS-DMA piece %4d B  lane order %d  %d k-steps in flight  LDS %3d KB  %8.3f ms  %7.1f GB/s  bytes %.0f\n", P, XORM, U, lds_kb, best,
+           bytes / best / 1e6, bytes);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const int64_t rows = argc > 1 ? atoll(argv[1]) : 100096, ncols = argc > 2 ? atoll(argv[2]) : 50048;
     const int64_t ldx = ncols + 128;
@@ -78,6 +130,22 @@ int main(int argc, char** argv) {
     CK(hipMemset(X, 0, sizeof(double) * rows * ldx));
     CK(hipDeviceSynchronize());
     printf("matrix %lld x %lld fp64 (%.1f GB), leading dimension %lld\n", (long long)rows, (long long)ncols, rows * ncols * 8e-9, (long long)ldx);
+    if (argc > 3 && atoi(argv[3]) == 1) {
+        // calibration set: ONE launch per shape (a counter pass attributes FETCH_SIZE per dispatch; the true byte count is
+        // rows x ncols x 8 for every one of them)
+        run_dma<64, 0, 3>(X, rows, ldx, ncols, out, 72, 1);
+        run_dma<64, 1, 3>(X, rows, ldx, ncols, out, 72, 1);
+        run_dma<64, 2, 3>(X, rows, ldx, ncols, out, 72, 1);
+        run_dma<128, 0, 2>(X, rows, ldx, ncols, out, 72, 1);
+        run_dma<256, 0, 2>(X, rows, ldx, ncols, out, 72, 1);
+        run_dma<1024, 0, 1>(X, rows, ldx, ncols, out, 72, 1);
+        run<64, 128, 6>(X, rows, ldx, ncols, out, 72);
+        run<128, 128, 3>(X, rows, ldx, ncols, out, 72);
+        run<1024, 64, 1>(X, rows, ldx, ncols, out, 72);
+        CK(hipFree(X));
+        CK(hipFree(out));
+        return 0;
+    }
     // two workgroups per CU (72 KB), as tail.hip's JT = 2
     run<64, 128, 6>(X, rows, ldx, ncols, out, 72);
     run<128, 128, 2>(X, rows, ldx, ncols, out, 72);
