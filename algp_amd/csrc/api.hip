@@ -434,7 +434,7 @@ struct Impl {
     // p0 .. Npad-1 (-1 = padding row, zero).
     static bool vt_rows_for_new_sites(algp_ctx* c, int64_t Nb, int64_t p0, std::vector<int64_t>& src_row,
                                       std::vector<int64_t>& lrow, std::vector<T>& lscale, bool& any_second) {
-        static const bool on = !(getenv("ALGP_FACTOR_FROM_VT") && atoi(getenv("ALGP_FACTOR_FROM_VT")) == 0);
+        static const bool on = env_switch("ALGP_FACTOR_FROM_VT", true);
         const int64_t N = c->N, Npad = c->Npad;
         if (!on || !c->Vt.p || c->vt_hyp_stamp != c->hyp_stamp || (int64_t)c->vt_fact_idx.size() < Nb || Nb <= 0) return false;
         if (c->vt_cand_idx != c->cand_idx || (int64_t)c->vt_kind.size() != c->M) return false;
@@ -875,13 +875,12 @@ struct Impl {
             // a 128-column block of the factor (tail.hip): HBM-bound, where re-solving the whole open 128-block walks all of
             // V^T on the matrix cores at full tile width (28 -> 13 ms per step at N = 50 000 x 100 000 candidates).
             // $ALGP_TAIL_COLS=0: the 128-column blocks as before.  Small problems keep them too (nothing to gain).
-            const bool tail_on = !(getenv("ALGP_TAIL_COLS") && atoi(getenv("ALGP_TAIL_COLS")) == 0);    // read per call: tests flip it
+            const bool tail_on = env_switch("ALGP_TAIL_COLS", true);                                 // read per call: tests flip it
             if (tail_on && p0 >= 2048 && Mpad >= 2048 && c->cur == c->stream) {
                 // exactly the appended rows [p0, N) when there are at most 64 of them (tail.hip handles any first column; the
-                // epilogue's inverse is that of a window of L around the range, solve_run); $ALGP_TAIL_EXACT=0: from the
-                // 16-column boundary below p0 to the one above N (rounds 3-4: 48 columns of MFMA work for 30 new rows)
-                const bool exact_on = !(getenv("ALGP_TAIL_EXACT") && atoi(getenv("ALGP_TAIL_EXACT")) == 0);
-                const bool exact = exact_on && N > p0 && N - p0 <= 64;
+                // epilogue's inverse is that of a window of L around the range, solve_run); more than 64: from the 16-column
+                // boundary below p0 to the one above N, as ranges of at most 64 columns
+                const bool exact = N > p0 && N - p0 <= 64;
                 const int64_t k16 = exact ? p0 : p0 / 16 * 16, c1 = exact ? N : round_up(N, 16);
                 int n = 0;
                 bool ok = c1 > k16;
@@ -892,10 +891,8 @@ struct Impl {
                     n = 1;
                 }
                 // at most 64 new columns: ONE pass over V^T even where they straddle two 128-column blocks of the factor (the
-                // epilogue then takes the inverse of the 128 x 128 window of L at (k16, k16), solve_run); $ALGP_TAIL_STRADDLE=0: a
-                // pass per block as before (16 ms instead of 9.5 for the 40 GB of config 5)
-                const bool straddle_on = !(getenv("ALGP_TAIL_STRADDLE") && atoi(getenv("ALGP_TAIL_STRADDLE")) == 0);
-                if (ok && !exact && straddle_on && c1 - k16 <= 64 && k16 / NB != (c1 - 1) / NB && k16 + NB <= Npad) {
+                // epilogue then takes the inverse of the 128 x 128 window of L at (k16, k16), solve_run)
+                if (ok && !exact && c1 - k16 <= 64 && k16 / NB != (c1 - 1) / NB && k16 + NB <= Npad) {
                     pl.seg_c0[0] = k16;
                     pl.seg_w[0] = (int)(c1 - k16);
                     pl.seg_window = true;
@@ -988,7 +985,7 @@ struct Impl {
     // candidates on 4-8 GPUs, a held-out set) runs as ONE task-list launch (chol_dag.hip without the factorisation's
     // own tasks; $ALGP_SOLVE_DAG=0: the launch sequences of potrf.hip); everything else is trsm_blocked.
     static int solve_run(algp_ctx* c, SolvePlan& pl) {
-        const bool solve_dag_on = !(getenv("ALGP_SOLVE_DAG") && atoi(getenv("ALGP_SOLVE_DAG")) == 0);   // read per call: tests flip it
+        const bool solve_dag_on = env_switch("ALGP_SOLVE_DAG", true);                                // read per call: tests flip it
         const int64_t Npad = c->Npad, Mpad = c->Mpad, ldc = c->ldv, keep = pl.keep;
         prof_span_begin(c, ALGP_PROF_TRSM, (double)(Npad - keep) * (double)(Npad + keep) * (double)Mpad,
                         sizeof(T) * (double)Mpad * (double)Npad);
@@ -1012,7 +1009,7 @@ struct Impl {
             // a from-scratch solve of more than 320 tile rows: its launches leave the rows' sums of v^2 and v z per column tile
             // (utils.py:301-304 needs nothing else of V^T), the 8 GB pass over V^T at config 4 falls away
             T* stat = nullptr;
-            const bool stats_on = !(getenv("ALGP_ROW_STATS") && atoi(getenv("ALGP_ROW_STATS")) == 0);      // read per call: tests flip it
+            const bool stats_on = env_switch("ALGP_ROW_STATS", true);                                  // read per call: tests flip it
             if (stats_on && keep == 0 && !pl.carried_sums && ensure(c, c->rowstat, sizeof(T) * 2 * (size_t)(Npad / NB) * (size_t)Mpad) == ALGP_OK)
                 stat = p(c->rowstat);
             trc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), Npad, c->Lld, p(c->invD), keep, p(c->z), stat,
@@ -1097,7 +1094,7 @@ struct Impl {
     // the factorisation, then the three-stream sweep of potrf.hip, which wins from ~55 000 rows on.  (Overlapping the two
     // as separate launch sequences on streams was measured in round 1 -- 207 vs 193 ms/step -- and removed.)
     static int fit_and_solve(algp_ctx* c) {
-        const bool fold_on = !(getenv("ALGP_FOLD") && atoi(getenv("ALGP_FOLD")) == 0);                  // read per call: tests flip it
+        const bool fold_on = env_switch("ALGP_FOLD", true);                                          // read per call: tests flip it
         if (!fold_on || c->M == 0 || !panel_fits(c->Npad, c->Mpad)) {
             ALGP_TRY(factorize(c, 0));
             return solve_candidates(c, 0, nullptr);
@@ -1108,9 +1105,8 @@ struct Impl {
         Panel pn{p(c->Vt), c->ldv, c->Mpad, 1, false};
         // a spare (padding) row of the candidates' last tile carries y - ybar through the launch: z = L^-1 (y - ybar) comes out
         // as that row of P L^-T, and the forward substitution behind the launch (0.41 ms at N = 10 000, with the machine
-        // idle) falls away ($ALGP_Z_IN_PANEL=0: the substitution)
-        static const bool z_on = !(getenv("ALGP_Z_IN_PANEL") && atoi(getenv("ALGP_Z_IN_PANEL")) == 0);
-        if (z_on && c->M < c->Mpad) {
+        // idle) falls away (a candidate count that fills its last tile keeps the substitution)
+        if (c->M < c->Mpad) {
             pn.z_row = c->M;
             ALGP_HIP(hipMemcpyAsync(p(c->Vt) + c->M * c->ldv, c->y0.p, sizeof(T) * c->Npad, hipMemcpyDeviceToDevice, c->stream));
         }
@@ -1669,7 +1665,7 @@ struct Impl {
     // c->scores must hold bounds for (ss, delta): otherwise (first pick after a solve, MI criterion, lazy greedy
     // switched off) every row is scored, which also brings every row up to date
     static int ensure_bounds(algp_ctx* c, int criterion, double static_std, double mobile_std, double ss, double delta) {
-        static const bool lazy_on = !(getenv("ALGP_LAZY_GREEDY") && atoi(getenv("ALGP_LAZY_GREEDY")) == 0);
+        static const bool lazy_on = env_switch("ALGP_LAZY_GREEDY", true);
         if (criterion != ALGP_CRIT_ENTROPY || !lazy_on || !c->bounds_valid || c->lazy_ss != ss || c->lazy_delta != delta)
             return scores_enqueue(c, criterion, static_std, mobile_std, nullptr);
         return ALGP_OK;
@@ -1963,11 +1959,10 @@ struct Impl {
         bool have_X = false, inv_enq = false;
         // Round 5: z rides along too (a dense tile row behind the identity that carries y - ybar), and alpha = X z is one pass
         // over the X the launch leaves -- no substitution chain runs beside S^-1 = X X^T any more (the two took 5.5 ms there,
-        // starved by the GEMM).  $ALGP_FIT_ONE_LAUNCH=0: round 4's form.  (X X^T as tasks of the same launch as well was built
+        // starved by the GEMM).  (X X^T as tasks of the same launch as well was built
         // and measured in round 5 -- the launch grew by what the separate 5.1-ms GEMM launch costs, 12.9 -> 18.9 ms at N = 10 000
         // fp64: the list leaves nothing idle to fill -- and removed again: EXPERIMENTS.md.)
-        static const bool one_launch = !(getenv("ALGP_FIT_ONE_LAUNCH") && atoi(getenv("ALGP_FIT_ONE_LAUNCH")) == 0);
-        const int64_t prow = (one_launch && grad_out) ? Npad + NB : Npad;
+        const int64_t prow = grad_out ? Npad + NB : Npad;
         if (c->N > 0 && panel_fits(Npad, prow)) {
             ALGP_TRY(ensure(c, c->auxW, sizeof(T) * prow * Npad));
             ALGP_TRY(ensure(c, c->auxA, sizeof(T) * Npad * Npad));
@@ -2058,7 +2053,7 @@ int algp_create(int device_id, int dtype, algp_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return ALGP_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) c->stream3 = nullptr;
     if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess) c->stream4 = nullptr;
-    if (const char* e = getenv("ALGP_TRSM_CHUNKS")) c->trsm_chunks = atoi(e);
+    c->trsm_chunks = env_int("ALGP_TRSM_CHUNKS", c->trsm_chunks);
     c->cur = c->stream;
     if (ensure(c, c->scal, sizeof(double) * SC_COUNT) != ALGP_OK) { hipStreamDestroy(c->stream); delete c; return ALGP_ERR_OOM; }
     hipMemsetAsync(c->scal.p, 0, sizeof(double) * SC_COUNT, c->stream);
@@ -2324,6 +2319,7 @@ int algp_comm_init_host(algp_ctx* c, int nranks, int rank, algp_allgather_fn fn,
     hipStreamSynchronize(c->stream);
     return comm_init_host(c, nranks, rank, fn, user);
 }
+#if ALGP_TEST_HOOKS
 int algp_debug_first_max(algp_ctx* c, const double* triples, int nranks, double out5[5]) {
     CHECK_CTX(c);
     if (!triples || nranks < 1 || nranks > 4096 || !out5) return fail(c, ALGP_ERR_BAD_ARG, "debug_first_max: bad arguments");
@@ -2340,6 +2336,7 @@ int64_t algp_debug_counter(algp_ctx* c, int which) {
         default: return -1;
     }
 }
+#endif
 int algp_comm_set_owners(algp_ctx* c, const int32_t* owner, int64_t n_pool) {
     CHECK_CTX(c);
     if (!owner) { c->site_owner.clear(); c->site_owner_hash = 0; return ALGP_OK; }
@@ -2353,14 +2350,12 @@ int algp_comm_set_owners(algp_ctx* c, const int32_t* owner, int64_t n_pool) {
     c->site_owner_hash = h;
     return ALGP_OK;
 }
+#if ALGP_TEST_HOOKS
 int algp_debug_set_trsm_chunks(algp_ctx* c, int chunks) {
     CHECK_CTX(c);
     if (chunks < 0 || chunks > 4) return fail(c, ALGP_ERR_BAD_ARG, "debug_set_trsm_chunks: 0 (default) .. 4");
     hipStreamSynchronize(c->stream);
-    if (chunks == 0) {
-        const char* e = getenv("ALGP_TRSM_CHUNKS");
-        chunks = e ? atoi(e) : 3;
-    }
+    if (chunks == 0) chunks = env_int("ALGP_TRSM_CHUNKS", 3);
     c->trsm_chunks = chunks;
     return ALGP_OK;
 }
@@ -2418,6 +2413,7 @@ int algp_debug_fail_at(algp_ctx* c, int where, int code) {
     else return fail(c, ALGP_ERR_BAD_ARG, "debug_fail_at: where = 0 (pick), 1 (commit), 2 (pack), 3 (row exchange)");
     return ALGP_OK;
 }
+#endif
 int algp_comm_destroy(algp_ctx* c) {
     CHECK_CTX(c);
     hipStreamSynchronize(c->stream);

@@ -53,11 +53,13 @@ static RcclApi* rccl_api(std::string* why) {
         tried = true;
         std::string loaded;
         dl_iterate_phdr(find_loaded_rccl, &loaded);
-        // $ALGP_RCCL_PATH, when set, is the only file tried (besides a copy the process has mapped already)
+        // $ALGP_RCCL_PATH, when set, is the ONLY file tried -- also in a process that has another librccl mapped already
+        // (PyTorch's): whoever sets it means that file.  Otherwise the mapped copy first (one RCCL per process), then the usual names.
         const char* envp = getenv("ALGP_RCCL_PATH");
         const bool only_env = envp && *envp;
-        const char* names[] = {loaded.empty() ? nullptr : loaded.c_str(), envp, only_env ? nullptr : "librccl.so.1",
-                               only_env ? nullptr : "librccl.so", only_env ? nullptr : "/opt/rocm/lib/librccl.so.1"};
+        const char* names[] = {only_env ? envp : nullptr, only_env || loaded.empty() ? nullptr : loaded.c_str(),
+                               only_env ? nullptr : "librccl.so.1", only_env ? nullptr : "librccl.so",
+                               only_env ? nullptr : "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (!n || !*n) continue;
             api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -178,7 +180,7 @@ int comm_init(algp_ctx* c, int nranks, int rank, const void* unique_id128) {
 }
 
 static bool gather_rows_on() {
-    static const bool on = !(getenv("ALGP_GATHER_ROWS") && atoi(getenv("ALGP_GATHER_ROWS")) == 0);
+    static const bool on = env_switch("ALGP_GATHER_ROWS", true);
     return on;
 }
 // bytes a rank contributes per pick: the 32-byte header, and the row when rows travel (fixed by the train set's size, which

@@ -1,5 +1,6 @@
 // Internal declarations shared by the HIP translation units of libalgp_hip.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -257,6 +258,25 @@ void prof_span_end(algp_ctx* c);
 void prof_span_end_on(algp_ctx* c, hipStream_t st);
 void prof_span_begin2(algp_ctx* c, int klass, double flops, double bytes);   // second span, starts on c->cur
 void prof_span_end2(algp_ctx* c);
+
+// ---- environment switches: ALL of them, read through these two functions ------------------------------------------------
+// Size-range fall-backs that are product paths for other sizes, each forced by its switch so that the tests can run both on
+// one input:   ALGP_TAIL_COLS=0 (appended columns re-solved as whole 128-column blocks: what inputs below 2 048 rows take),
+//   ALGP_TAIL_SPLIT=0 (the tail kernel without its k-split), ALGP_SOLVE_DAG=0 (mid-sized solves as the right-looking push
+//   instead of the task list), ALGP_FOLD=0 (fit and solve as two steps: what a candidate set beyond 51 200 rows takes),
+//   ALGP_ROW_STATS=0 / ALGP_TRSM_INV512=0 (the chunked solve with a variance pass / with 128-column steps inside a block),
+//   ALGP_FACTOR_FROM_VT=0 (new rows of an updated factor solved, not gathered), ALGP_LAZY_GREEDY=0 (every row scored before
+//   every pick), ALGP_TRSM_CHUNKS=n (row-chunk streams of the big solve; bench.py's one-stream leg sets it by the ABI).
+// Cross-check routes: ALGP_CHOL_DAG=0 (launch-sequence factorisation), ALGP_GATHER_ROWS=0 (remote commits rebuild the row).
+// Tooling: ALGP_LAUNCH_LOG=<file> (tools/trace_shapes.py), ALGP_RCCL_PATH=<file> (which librccl to dlopen).
+inline bool env_switch(const char* name, bool dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) != 0 : dflt;
+}
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
 
 #define ALGP_HIP(call)                                                                          \
     do {                                                                                        \

@@ -134,7 +134,7 @@ int cholesky_dag(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* l
 
 // ALGP_CHOL_DAG=0 selects the launch sequences for every size (A/B runs, tests of the fallback)
 bool dag_enabled() {
-    static const int dag = getenv("ALGP_CHOL_DAG") ? atoi(getenv("ALGP_CHOL_DAG")) : 1;
+    static const int dag = env_int("ALGP_CHOL_DAG", 1);
     return dag != 0;
 }
 
@@ -269,9 +269,7 @@ static int trsm_rows_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t
         //   helper: wait a[J] . P(J) . record b[J]                            P = push into everything beyond the next block
         // Every column block receives its pushes in ascending J (P(J-1) before Q(J), both before I(J+1)).
         constexpr int64_t PW = WB;                                  // (1024-wide pushes: 25.2 ms at 12 500 rows, 41.9 at 25 000)
-        // ($ALGP_TRSM_PUSH_STREAMS=1: everything on the caller's stream -- the same arithmetic, for the cross-check in the tests)
-        const bool one_stream = getenv("ALGP_TRSM_PUSH_STREAMS") && atoi(getenv("ALGP_TRSM_PUSH_STREAMS")) == 1;
-        hipStream_t sa = c->cur, sb = (!one_stream && c->cur == c->stream && c->stream2) ? c->stream2 : nullptr;
+        hipStream_t sa = c->cur, sb = (c->cur == c->stream && c->stream2) ? c->stream2 : nullptr;
         int rc = ALGP_OK;
         int64_t jb = 0;
         for (int64_t j0 = 0; j0 < npad && rc == ALGP_OK; j0 += PW, ++jb) {
@@ -374,19 +372,10 @@ int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T
 // C (lower tiles) <- X X^T for the upper-triangular X above: ONE launch in which output tile (a, b <= a) sums over the
 // columns k >= 128 a only (row tile a of X is zero left of them; GemmArgs::ktri).  The tiles are dealt out by ascending a,
 // i.e. longest K first, so the 512 resident workgroups end within one short tile of each other.  (Rounds 1-3: a sum over
-// 512-wide column panels of X, 20 launches whose first few hold fewer tiles than the machine has slots; $ALGP_SYRK_PANELS=1.)
+// 512-wide column panels of X, 20 launches whose first few hold fewer tiles than the machine has slots.)
 template <typename T>
 int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T* C, int64_t ldc) {
-    const bool panels = getenv("ALGP_SYRK_PANELS") && atoi(getenv("ALGP_SYRK_PANELS")) == 1;
-    if (!panels)
-        return gemm_nt_launch_batched<T>(c, klass, npad, npad, npad, (T)1, X, ldx, 0, X, ldx, 0, (T)0, nullptr, ldc, 0, C, ldc, 0, 1, 1, 1);
-    const int64_t last = (npad - 1) / WB * WB;
-    for (int64_t kp = last; kp >= 0; kp -= WB) {
-        const int64_t w = (npad - kp < WB) ? npad - kp : WB, m = kp + w;
-        ALGP_TRY(gemm_nt_launch<T>(c, klass, m, m, w, (T)1, X + kp, ldx, X + kp, ldx, kp == last ? (T)0 : (T)1, C, ldc, C,
-                                   ldc, 1));
-    }
-    return ALGP_OK;
+    return gemm_nt_launch_batched<T>(c, klass, npad, npad, npad, (T)1, X, ldx, 0, X, ldx, 0, (T)0, nullptr, ldc, 0, C, ldc, 0, 1, 1, 1);
 }
 template int syrk_upper<double>(algp_ctx*, int, const double*, int64_t, int64_t, double*, int64_t);
 template int syrk_upper<float>(algp_ctx*, int, const float*, int64_t, int64_t, float*, int64_t);
@@ -429,7 +418,7 @@ int trsm_blocked(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, const 
     const T* inv512 = nullptr;
     T* tmp512 = nullptr;
     {
-        const bool on = !(getenv("ALGP_TRSM_INV512") && atoi(getenv("ALGP_TRSM_INV512")) == 0);      // read per call: tests flip it
+        const bool on = env_switch("ALGP_TRSM_INV512", true);                                      // read per call: tests flip it
         if (on && col_start == 0 && tiles > TRSM_PUSH_TILES && npad / WB >= 1 && c->cur == c->stream &&
             ensure(c, c->inv512, sizeof(T) * (size_t)(npad / WB) * WB * WB) == ALGP_OK &&
             ensure(c, c->inv512_scr, sizeof(T) * inv512_scratch_elems<T>(npad)) == ALGP_OK &&

@@ -357,7 +357,7 @@ static int tail_dispatch(algp_ctx* c, TailArgs<T>& g, int64_t mpad, int nkt, int
     const int nrb = (int)(mpad / (64 * JT)), slots = 256 * tail_occ(nt, JT);
     int best = 1;
     {
-        static const bool split_on = !(getenv("ALGP_TAIL_SPLIT") && atoi(getenv("ALGP_TAIL_SPLIT")) == 0);
+        static const bool split_on = env_switch("ALGP_TAIL_SPLIT", true);
         auto eff = [&](int s_) { const double r = (double)s_ * nrb / slots; return r / ceil(r); };
         double be = eff(1);
         // worth two launches and the partials' round trip only where the plain launch wastes more than 6 % of the machine
@@ -422,9 +422,8 @@ int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
     g.part = nullptr;
     const int nkt = (int)(c0 / (16 / sizeof(T) * 8));
     ProfScope ps(c, klass, 2.0 * (double)mpad * (double)c0 * w, sizeof(T) * ((double)mpad * (double)c0 + 64.0 * (double)c0));
-    // $ALGP_TAIL_ROWS=64: 64 candidate rows per workgroup (three or four workgroups per CU) instead of 128 (two)
-    static const bool rows64 = getenv("ALGP_TAIL_ROWS") && atoi(getenv("ALGP_TAIL_ROWS")) == 64;
-    return rows64 ? tail_dispatch<T, 1>(c, g, mpad, nkt, w) : tail_dispatch<T, 2>(c, g, mpad, nkt, w);
+    // 128 candidate rows per workgroup, two workgroups per CU (64 rows at three or four per CU: the same time, EXPERIMENTS.md)
+    return tail_dispatch<T, 2>(c, g, mpad, nkt, w);
 }
 template int tail_cols_launch<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*, int64_t, int64_t, const double*, int64_t, int,
                                       const double*);

@@ -119,21 +119,22 @@ def cpu_baseline(w, hyp_vals, args):
     sel = np.sort(np.random.RandomState(0).permutation(N)[:Ns])
     X = w['pool'][:N][sel]
     var = w['var'][sel]
-    ncand = 2
-    xc = w['pool'][N:N + ncand]
+    ncand = 8                                                     # timed one by one: the printed rate is the MEDIAN candidate's (round 5: the
+    xc = w['pool'][N:N + ncand]                                   # mean of 2, and the figure wandered +-25 % between runs)
 
-    def faithful():
+    def fit_once():
         t0 = time.time()
         cov_aa = O.cov_mat_ref(hyp, X, None, var, True, dtype=np.float32)
         inv = np.linalg.inv(cov_aa)
         inv @ (w['y'][sel] - w['y'][sel].mean()).astype(np.float32)
-        t_fit = time.time() - t0
+        return time.time() - t0
+
+    def candidate_once(i):
         t0 = time.time()
-        for i in range(ncand):
-            Xa = np.vstack([X, xc[i:i + 1]])
-            cov_a = O.cov_mat_ref(hyp, Xa, None, None, True, dtype=np.float32) + np.diag(np.r_[var, 0.01])
-            O.entropy_from_cov_ref(cov_a)
-        return t_fit, (time.time() - t0) / ncand
+        Xa = np.vstack([X, xc[i:i + 1]])
+        cov_a = O.cov_mat_ref(hyp, Xa, None, None, True, dtype=np.float32) + np.diag(np.r_[var, 0.01])
+        O.entropy_from_cov_ref(cov_a)
+        return time.time() - t0
 
     from scipy.linalg import solve_triangular
     ms = 2048
@@ -148,10 +149,11 @@ def cpu_baseline(w, hyp_vals, args):
         assert np.all(pv > 0)
         return time.time() - t0
 
-    faithful()                                                    # warm-up (BLAS thread pool, page faults)
-    runs = [faithful() for _ in range(3)]
-    t_fit = float(np.median([r[0] for r in runs]))
-    t_cand = float(np.median([r[1] for r in runs]))
+    fit_once()                                                    # warm-up (BLAS thread pool, page faults)
+    candidate_once(0)
+    t_fit = float(np.median([fit_once() for _ in range(3)]))
+    cand_times = [candidate_once(i) for i in range(ncand)]
+    t_cand = float(np.median(cand_times))
     efficient()
     t_eff = float(np.median([efficient() for _ in range(3)]))
     k = args.picks
@@ -163,8 +165,9 @@ def cpu_baseline(w, hyp_vals, args):
         'value': M / t_step, 'unit': 'candidates/s', 'cores': cores, 'kind': 'port',
         'blas': blas, 'blas_threads': threads, 'os_cpu_count': os.cpu_count(),
         'sample': 'reference-faithful oracle (fp32 kernel, np.linalg.inv, one slogdet per candidate) at '
-                  'N=%d of %d train, %d of %d candidates, 1 of %d picks; 1 warm-up + median of 3 runs (fit %.2fs, %.2fs per '
-                  'candidate); extrapolated x(N/Ns)^3, linear in candidates x picks' % (Ns, N, ncand, M, k, t_fit, t_cand),
+                  'N=%d of %d train, %d of %d candidates each timed on its own, 1 of %d picks; 1 warm-up, then the median of 3 fits '
+                  '(%.2fs) and the median candidate (%.2fs; min %.2f, max %.2f); extrapolated x(N/Ns)^3, linear in candidates x picks'
+                  % (Ns, N, ncand, M, k, t_fit, t_cand, min(cand_times), max(cand_times)),
         'ms_per_step_extrapolated': 1e3 * t_step,
         'efficient_cpu_candidates_per_s': M / t_eff_step,
         'efficient_cpu_sample': 'numpy/scipy Cholesky + triangular solve + variance, N=%d, %d candidates, median of 3: %.2fs; '
@@ -637,7 +640,7 @@ def strong_emulation(ctx, _hip, res, args):
     are known from the one-rank run (picks are identical by construction, and that run holds every candidate's row), so it
     answers (-inf, -1, 0) for every absent rank except the winner's owner, whose true contribution it supplies.  Timed for
     the first and the last rank of each n.  Left out: the wire time of RCCL's all-gather (n x 80 KB per pick) and skew
-    between ranks; the host transport used here costs two stream synchronisations and ~0.7 MB of PCIe traffic per pick
+    between ranks; the host transport used here costs one stream synchronisation and ~0.7 MB of PCIe traffic per pick
     instead, plus the Python callback."""
     import ctypes
     import struct
@@ -1014,11 +1017,18 @@ def main():
                 picks, _ = sg.greedy(_hip.CRIT_ENTROPY, w['static_std'], w['mobile_std'], args.picks)
             picks_log.append([int(p) for p in picks])
 
-        def timed(nsteps):
+        step_ms = []                                              # every timed step's own duration: a step ends with its picks on the host
+
+        def timed(nsteps, log=None):
             barrier()
             t0 = time.perf_counter()
+            t_prev = t0
             for _ in range(nsteps):
                 step()
+                if log is not None:                               # (no synchronisation of its own: the last pick's read-back is one)
+                    t_now = time.perf_counter()
+                    log.append(1e3 * (t_now - t_prev))
+                    t_prev = t_now
             barrier()
             el = time.perf_counter() - t0
             if dist is not None:
@@ -1034,15 +1044,30 @@ def main():
         ctx.prof_enable(True)
         ctx.prof_reset()
         s0 = ctx.sync_count()
-        elapsed = timed(args.steps)
+        elapsed = timed(args.steps, step_ms)
         syncs = ctx.sync_count() - s0
         prof = {k: ctx.prof_get(k) for k in _hip.PROF}
         chol_stats = ctx.cholesky_task_stats()
         ctx.prof_enable(False)
         elapsed_unprof = timed(args.steps)
+        # SURVEY 8(d)'s second clock: host wall time around the ABI with the inputs handed over as host NumPy buffers every
+        # step -- pool coordinates, train set and candidate list up (H2D inside the calls), the picks back on the host -- where
+        # the headline's steps start from resident inputs (reference utils.py:293-319 is host-in / host-out)
+        host_ms = []
+        if world == 1:
+            picks_resident = picks_log[-1]
+            for _ in range(max(3, min(args.steps, 10))):
+                barrier()
+                t0 = time.perf_counter()
+                ctx.set_pool(w['pool'])
+                ctx.set_train(np.arange(N), w['y'], w['var'])
+                ctx.set_candidates(mine, prior_includes_noise=True)
+                step()
+                host_ms.append(1e3 * (time.perf_counter() - t0))
+            assert picks_log[-1] == picks_resident, 'the host-inclusive step picked other candidates'
         return dict(w=w, N=N, total_c=total_c, Mloc=int(w['counts'][rank]), M0=int(w['counts'][0]), elapsed=elapsed,
                     elapsed_unprof=elapsed_unprof, prof=prof, chol_stats=chol_stats, picks=picks_log[-1], step=step,
-                    syncs_per_step=syncs / float(args.steps))
+                    syncs_per_step=syncs / float(args.steps), step_ms=step_ms, host_ms=host_ms)
 
     want = args.scaling
     res = run_case('weak' if want == 'weak' else 'strong')
@@ -1146,6 +1171,13 @@ def main():
             'unit': 'candidates/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup,
             'ms_per_step': ms_step,
+            'ms_per_step_median': float(np.median(res['step_ms'])) if res['step_ms'] else None,
+            'ms_per_step_p95': _pct(np.array(res['step_ms']), 95) if res['step_ms'] else None,
+            'ms_per_step_host_inclusive': float(np.median(res['host_ms'])) if res['host_ms'] else None,
+            'host_inclusive_note': ('median of %d steps that hand the pool coordinates (%d x 2), the train set and the candidate list over as host '
+                                    'NumPy buffers inside the clock (algp_set_pool / algp_set_train / algp_set_candidates: H2D in the calls) and '
+                                    'return the picks to the host; ms_per_step / _median / _p95: inputs resident, rank 0\'s own clock per step'
+                                    % (len(res['host_ms']), N + total_c)) if res['host_ms'] else None,
             'ms_per_step_unprofiled': 1e3 * elapsed_unprof / K,
             'value_unprofiled': total_c / (elapsed_unprof / K),
             'higher_is_better': True, 'scaling': 'weak' if want == 'weak' else 'strong', 'vs_baseline': None,

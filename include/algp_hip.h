@@ -216,8 +216,9 @@ int algp_greedy(algp_ctx* ctx, int criterion, double static_std, double mobile_s
 int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen, double mobile_std, double* dH_out);
 
 /* ---- (e) multi-GPU: the loop over candidates (agent.py:317-347) cut into shards, one process and one ctx per GPU ----
- * Every rank factorises the same train set (algp_factorize / algp_fit_and_solve) and holds a contiguous slice of the
- * candidate list (algp_set_candidates + a solve; a slice may be empty).  The only communication of the path is ONE
+ * Every rank factorises the same train set (algp_factorize / algp_fit_and_solve) and holds a share of the candidate list
+ * (algp_set_candidates + a solve; ANY partition -- contiguous slices, the strided owner map of algp_comm_set_owners below --
+ * and a share may be empty: the first maximum breaks ties by the smaller pool index whatever the shards).  The only communication of the path is ONE
  * all-gather per pick, issued by the library on the context's stream: each rank contributes 32 bytes -- (its best local
  * utility, that candidate's pool index, a status word, the candidate's statistic) -- plus that candidate's row of V^T
  * (Npad + 128 elements: ~80 KB at N = 10 000 fp64), so that a rank which does not own the winner copies the winner's row
@@ -245,8 +246,11 @@ int algp_score_paths(algp_ctx* ctx, const int64_t* sites, int npaths, int maxlen
  * The active-learning LOOP on sharded candidates (agent.py:125-229: greedy :141 -> _add_samples :66-82 -> predict :196-210,
  * with the loop of agent.py:313-354 cut into shards) -- algp_comm_set_owners: owner[q] = the rank that holds pool site q as
  *   a candidate (-1: nobody; NULL clears the map), the same array on every rank, after algp_comm_init[_host] and
- *   algp_set_pool.  With a map attached algp_factorize_update becomes a COLLECTIVE (every rank calls it with the same
- *   train set): the sites a step appends to the train set are candidates of one rank each, and that rank's row of V^T is
+ *   algp_set_pool (which DROPS a map attached before it: the map belongs to its pool; the communicator stays -- it is
+ *   joined once per context).  With a map attached algp_factorize_update becomes a COLLECTIVE whatever a rank finds locally
+ *   -- a rank that keeps nothing of its factor (an earlier factorisation failed, other hyper-parameters) or cannot
+ *   re-allocate it still enters the agreement and says so there; the agreement word also carries a hash of the whole map
+ *   (every rank calls it with the same train set): the sites a step appends to the train set are candidates of one rank each, and that rank's row of V^T is
  *   the site's new row of the replicated factor left of the tail block -- so instead of solving those rows against the
  *   kept factor on every rank (38 ms per 256 rows at N = 50 000) the ranks exchange them: a 32-byte agreement word per
  *   rank (status, first changed row, train size, a hash of the plan), then ONE all-gather of cap rows of the kept width
@@ -268,6 +272,14 @@ int algp_comm_init_host(algp_ctx* ctx, int nranks, int rank, algp_allgather_fn f
 int algp_comm_destroy(algp_ctx* ctx);
 int algp_greedy_sharded(algp_ctx* ctx, int criterion, double static_std, double mobile_std, int k, int64_t* picks_out,
                         double* utilities_out);
+/* ---- test hooks -----------------------------------------------------------------------------------------------------
+ * Compiled in when ALGP_TEST_HOOKS is 1 -- the default of algp_amd/csrc/Makefile, and what this repository's tests and
+ * bench.py (its one-stream leg, the strong-scaling emulation) need; `make TEST_HOOKS=0` builds the library without them
+ * (tests/test_abi.py checks that such an object exports no algp_debug_* symbol). */
+#ifndef ALGP_TEST_HOOKS
+#define ALGP_TEST_HOOKS 1
+#endif
+#if ALGP_TEST_HOOKS
 /* Test hooks of the exchange (no reference counterpart).  algp_debug_first_max: the reduction kernel of the gather on a
  * caller-made buffer of nranks triples (utility, pool index or -1, status) -> out5 = (utility, pool index, owner rank,
  * status, first rank with a non-zero status).  algp_debug_fail_next_pick: this rank reports `code` (an ALGP_ERR_* >= 2)
@@ -303,6 +315,7 @@ int algp_debug_set_trsm_chunks(algp_ctx* ctx, int chunks);
 int algp_debug_fail_next_pick(algp_ctx* ctx, int code);
 int algp_debug_dag_stall(algp_ctx* ctx, int ticket);
 int64_t algp_debug_counter(algp_ctx* ctx, int which);
+#endif /* ALGP_TEST_HOOKS */
 
 /* ---- a5 / a8: entropy_from_cov (utils.py:188-194) and set entropies for best_path --------
  * algp_entropy_from_cov: k*CONST + 1/2 log det cov for a host k x k SPD matrix.

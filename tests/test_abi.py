@@ -89,3 +89,18 @@ def test_bench_self_spawn_command_line(monkeypatch):
     assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '8'
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-6:] == ['--gpus', '8', '--steps', '2', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+
+
+def test_a_build_without_test_hooks_exports_no_debug_symbol(tmp_path):
+    """`make TEST_HOOKS=0` (-DALGP_TEST_HOOKS=0): the C-ABI translation unit compiled that way (host side only: seconds)
+    defines every product entry point and none of the nine algp_debug_* hooks (include/algp_hip.h, section "test hooks")."""
+    import subprocess
+    obj = tmp_path / 'api_nohooks.o'
+    csrc = os.path.join(REPO, 'algp_amd', 'csrc')
+    r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O1', '-std=c++17', '-fPIC', '-DALGP_TEST_HOOKS=0', '-I' + csrc,
+                        '--cuda-host-only', '-c', os.path.join(csrc, 'api.hip'), '-o', str(obj)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    syms = subprocess.run(['nm', str(obj)], capture_output=True, text=True).stdout
+    defined = set(re.findall(r' T (algp_[a-z0-9_]+)', syms))
+    assert not [s for s in defined if s.startswith('algp_debug_')], defined
+    assert 'algp_greedy_sharded' in defined and 'algp_fit_and_solve' in defined and len(defined) >= 50

@@ -92,7 +92,7 @@ def test_switch_reproduces_default(default_run, switch, exact):
             assert abs(a - b) <= (0.0 if exact else 1e-9 * max(1.0, abs(b))), (switch, name, a, b)
 
 
-# ---- round 5's switches: the tail kernel's forms and z as a row of the panel -----------------------------------------------
+# ---- the fall-back routes of the incremental step and of fit + solve ---------------------------------------------------------
 _STEP5 = r"""
 import json, sys
 import numpy as np
@@ -131,7 +131,7 @@ print(json.dumps(out))
 
 def _run5(env_extra):
     env = dict(os.environ)
-    for k in ('ALGP_TAIL_EXACT', 'ALGP_TAIL_STRADDLE', 'ALGP_TAIL_SPLIT', 'ALGP_TAIL_COLS', 'ALGP_TAIL_ROWS', 'ALGP_Z_IN_PANEL', 'ALGP_FIT_ONE_LAUNCH'):
+    for k in ('ALGP_TAIL_SPLIT', 'ALGP_TAIL_COLS', 'ALGP_FOLD', 'ALGP_SOLVE_DAG'):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, '-c', _STEP5], env=env, capture_output=True, text=True, timeout=300)
@@ -144,12 +144,14 @@ def default_run5():
     return _run5({})
 
 
-@pytest.mark.parametrize('switch', ['ALGP_TAIL_EXACT=0', 'ALGP_TAIL_EXACT=0 ALGP_TAIL_STRADDLE=0', 'ALGP_TAIL_SPLIT=0', 'ALGP_TAIL_COLS=0',
-                                    'ALGP_TAIL_ROWS=64', 'ALGP_TAIL_ROWS=64 ALGP_TAIL_SPLIT=0', 'ALGP_Z_IN_PANEL=0', 'ALGP_FIT_ONE_LAUNCH=0'])
-def test_round5_switch_reproduces_default(default_run5, switch):
-    """Every form the tail kernel replaced (16-aligned columns, a pass per 128-column block, one workgroup per 128 rows, the
-    128-column blocks), its 64-row workgroups (three per CU), and z by a substitution launch instead of a row of the panel: the same posterior, log-determinant,
-    MLL and gradient to rounding.  (Reference: agent.py:210 refits from scratch at every step; models.py:145-158.)"""
+@pytest.mark.parametrize('switch', ['ALGP_TAIL_SPLIT=0', 'ALGP_TAIL_COLS=0', 'ALGP_FOLD=0', 'ALGP_SOLVE_DAG=0'])
+def test_fallback_route_reproduces_default(default_run5, switch):
+    """The size-range fall-backs that stay in the library (csrc/common.h lists every switch): the tail kernel without its
+    k-split, appended columns re-solved as whole 128-column blocks (what inputs below 2 048 rows take), fit and solve as two
+    steps, the mid-sized solve as launches instead of the task list -- the same posterior, log-determinant, MLL and gradient
+    to rounding.  (Round 5's A/B-only switches -- ALGP_TAIL_EXACT / _STRADDLE / _ROWS, ALGP_Z_IN_PANEL, ALGP_FIT_ONE_LAUNCH,
+    ALGP_SYRK_PANELS, ALGP_TRSM_PUSH_STREAMS -- and their branches are gone.)  Reference: agent.py:210 refits from scratch at
+    every step; models.py:145-158."""
     got, ref = _run5(dict(kv.split('=') for kv in switch.split())), default_run5
     assert ref['b']['kept'] == 2260 and ref['c']['kept'] == 2283                      # exactly the appended columns by default
     for tag in ('a', 'b', 'c'):

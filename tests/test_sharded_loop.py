@@ -149,6 +149,23 @@ assert kept > 0 and sh.counter(4) == fb + 1 and sh.counter(1) == 0
 relock(ref, allc)
 ref.set_train(A2, y2, var2); ref.factorize(incremental=True)
 assert abs(ref.logdet() - sh.logdet()) < 1e-9 * abs(ref.logdet())
+# ... and a rank whose resident factor is void (its hyper-parameter stamp moved: keep = 0) while its peer keeps its blocks:
+# the incremental call is a collective all the same (ADVICE r5: the rank used to skip the agreement its peer waits in) --
+# the peer falls back to the solve, this rank factorises from scratch, both end with the one-rank factor
+relock(sh, mine)
+fb = sh.counter(4)
+if rank == 1:
+    sh.set_hypers(HYP.log_lengthscale, HYP.log_outputscale, HYP.log_noise)    # the same values: only the stamp moves
+sh.set_train(A2, y2, var2)
+kept = sh.factorize(incremental=True)
+assert (kept == 0) == (rank == 1), (rank, kept)
+assert sh.counter(4) == fb + 1, (rank, sh.counter(4), fb)
+assert abs(ref.logdet() - sh.logdet()) < 1e-9 * abs(ref.logdet())
+# a new pool drops the owner map (it belongs to the pool it was given for): the next incremental call is rank-local again
+sh.set_pool(X)
+sh.set_train(A2, y2, var2)
+sh.factorize(incremental=True)
+assert abs(ref.logdet() - sh.logdet()) < 1e-9 * abs(ref.logdet())
 dist.barrier()
 if rank == 0:
     print('SHARDED_LOOP_OK', LAYOUT, peers_total)

