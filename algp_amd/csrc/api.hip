@@ -1192,10 +1192,10 @@ struct Impl {
     }
 
     // ------------------------------------------------------------------ set entropies / inverse diagonals
-    static int build_set_matrix(algp_ctx* c, const int64_t* idx, int64_t m, const void* var, int64_t* mpad_out) {
+    static int build_set_matrix(algp_ctx* c, const int64_t* idx, int64_t m, const void* var, int64_t* mpad_out, T* dst = nullptr) {
         const int64_t mpad = round_up(std::max<int64_t>(m, 1), NB);
         *mpad_out = mpad;
-        ALGP_TRY(ensure(c, c->auxA, sizeof(T) * mpad * mpad));
+        if (!dst) ALGP_TRY(ensure(c, c->auxA, sizeof(T) * mpad * mpad));
         ALGP_TRY(ensure(c, c->auxInv, sizeof(T) * mpad * NB));
         ALGP_TRY(ensure(c, c->auxIdx, sizeof(int64_t) * mpad));
         ALGP_TRY(ensure(c, c->auxVar, sizeof(T) * mpad));
@@ -1204,7 +1204,7 @@ struct Impl {
             ALGP_HIP(hipMemcpyAsync(c->auxVar.p, var, sizeof(T) * m, hipMemcpyHostToDevice, c->stream));
         KmatSrc s = make_src(c);
         return kmat_launch<T>(c, s, (const int64_t*)c->auxIdx.p, m, mpad, (const int64_t*)c->auxIdx.p, m, mpad,
-                              var ? (const T*)c->auxVar.p : nullptr, c->pool_is_cov ? 0 : 1, nullptr, 1, p(c->auxA),
+                              var ? (const T*)c->auxVar.p : nullptr, c->pool_is_cov ? 0 : 1, nullptr, 1, dst ? dst : p(c->auxA),
                               mpad);
     }
 
@@ -1345,12 +1345,13 @@ struct Impl {
         const int64_t mb = (int64_t)Abar.size();
         const int64_t npad = round_up(std::max<int64_t>(n, 1), NB), mbpad = round_up(std::max<int64_t>(mb, 1), NB);
         {
-            // Three pool-wide matrices are alive at once (one factor being inverted + the two resident inverses): say so
-            // with the byte count instead of failing half-way through the allocations.  At the C4 size (110 000 sites,
-            // fp64) that is 290 GB -- and, more to the point, 2 x n^3/3 = 9e14 flop for the first pick.
-            const size_t need = sizeof(T) * ((size_t)npad * npad * 2 + (size_t)mbpad * mbpad + (size_t)npad * NB +
+            // Two pool-wide matrices stay resident -- each is built, factored and inverted IN its buffer (L in the strictly
+            // lower tiles, X = L^-T on and above the diagonal: trinv_upper_inplace) -- say so with the byte count instead of
+            // failing half-way through the allocations.  At config 4's own pool (110 000 sites, fp64) that is 2 x 96.8 GB
+            // (round 5 held a third matrix, the factor being inverted: 290 GB) and 4 n^3 / 3 = 1.8e15 flop for the first pick.
+            const size_t need = sizeof(T) * ((size_t)npad * npad + (size_t)mbpad * mbpad + (size_t)npad * NB +
                                              (size_t)MAX_APPEND * (npad + mbpad));
-            const size_t held = c->auxA.cap + c->auxInv.cap + c->miXbar.cap + c->miXall.cap + c->miU.cap + c->miW.cap;
+            const size_t held = c->auxInv.cap + c->miXbar.cap + c->miXall.cap + c->miU.cap + c->miW.cap;
             size_t free_b = 0, total_b = 0;
             ALGP_HIP(hipMemGetInfo(&free_b, &total_b));
             if (need > held + free_b)
@@ -1374,23 +1375,21 @@ struct Impl {
         // C_AbarAbar carries no measurement noise (agent.py:331)
         if (mb > 0) {
             int64_t mp;
-            ALGP_TRY(build_set_matrix(c, Abar.data(), mb, nullptr, &mp));
+            ALGP_TRY(build_set_matrix(c, Abar.data(), mb, nullptr, &mp, p(c->miXbar)));
             double ld = 0;
-            ALGP_TRY(factor_resident(c, p(c->auxA), mb, mbpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
+            ALGP_TRY(factor_resident(c, p(c->miXbar), mb, mbpad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
             H_bar = (double)mb * ENT_CONST + 0.5 * ld;
-            ALGP_TRY(set_identity_launch<T>(c, p(c->miXbar), mbpad, mbpad));
-            ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->miXbar), mbpad, mbpad, p(c->auxA), mbpad, p(c->auxInv)));
-            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXbar), mb, mbpad, mbpad, (const T*)nullptr, p(c->miDP), (T*)nullptr));
+            ALGP_TRY(trinv_upper_inplace<T>(c, ALGP_PROF_GEMM_OTHER, p(c->miXbar), mbpad, mbpad, p(c->auxInv)));
+            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXbar), mb, mbpad, mbpad, (const T*)nullptr, p(c->miDP), (T*)nullptr, 0));
         }
         {
             int64_t np2;
-            ALGP_TRY(build_set_matrix(c, all.data(), n, vall.data(), &np2));
+            ALGP_TRY(build_set_matrix(c, all.data(), n, vall.data(), &np2, p(c->miXall)));
             double ld = 0;
-            ALGP_TRY(factor_resident(c, p(c->auxA), n, npad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
+            ALGP_TRY(factor_resident(c, p(c->miXall), n, npad, p(c->auxInv), SC_AUXLOGDET, SC_AUXINFO, &ld));
             H_all = (double)n * ENT_CONST + 0.5 * ld;
-            ALGP_TRY(set_identity_launch<T>(c, p(c->miXall), npad, npad));
-            ALGP_TRY(trinv_upper<T>(c, ALGP_PROF_GEMM_OTHER, p(c->miXall), npad, npad, p(c->auxA), npad, p(c->auxInv)));
-            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXall), n, npad, npad, (const T*)nullptr, p(c->miDQ), (T*)nullptr));
+            ALGP_TRY(trinv_upper_inplace<T>(c, ALGP_PROF_GEMM_OTHER, p(c->miXall), npad, npad, p(c->auxInv)));
+            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXall), n, npad, npad, (const T*)nullptr, p(c->miDQ), (T*)nullptr, 0));
         }
         const double Hs[3] = {H_A, H_bar, H_all};
         ALGP_HIP(hipMemcpyAsync(c->miH.p, Hs, sizeof(Hs), hipMemcpyHostToDevice, c->stream));
@@ -1419,13 +1418,16 @@ struct Impl {
             // the site leaves the complement: column of P = X X^T at its row, then the rank-1 removal
             const int64_t cb = c->mi_posbar[pk.pool_idx];
             if (cb < 0) return fail(c, ALGP_ERR_STATE, "mutual_information: a picked site is missing from the complement set");
-            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXbar), c->mi_mb, mbpad, mbpad, p(c->miXbar) + cb * mbpad, (T*)nullptr, p(c->miCol)));
+            // column cb of P = X X^T: X's row cb is zero (the buffer holds L there) left of its own diagonal tile
+            ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXbar), c->mi_mb, mbpad, mbpad, p(c->miXbar) + cb * mbpad, (T*)nullptr, p(c->miCol),
+                                           cb / NB * NB));
             ALGP_TRY(mi_rank1_launch<T>(c, c->mi_mb, p(c->miCol), p(c->miU), mbpad, Hs + 3, c->mi_nbar, cb, 0, 0.0, p(c->miDP), Hs + 1,
                                         (double*)nullptr, lp));
             c->mi_nbar += 1;
         }
         // its noise in C + D_all changes by ss (new site: 0 -> ss) or by v_fused - sm (mobile-sampled site)
-        ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXall), n, npad, npad, p(c->miXall) + pk.pool_idx * npad, (T*)nullptr, p(c->miCol)));
+        ALGP_TRY(rows_reduce_launch<T>(c, p(c->miXall), n, npad, npad, p(c->miXall) + pk.pool_idx * npad, (T*)nullptr, p(c->miCol),
+                                       pk.pool_idx / NB * NB));
         ALGP_TRY(mi_rank1_launch<T>(c, n, p(c->miCol), p(c->miW), npad, Hs + 3 + MAX_APPEND, r, pk.pool_idx, 1, pk.in_train ? delta : ss,
                                     p(c->miDQ), Hs + 2, Hs + 0, lp));
         return ALGP_OK;

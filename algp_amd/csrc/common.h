@@ -408,6 +408,8 @@ int tail_cols_launch(algp_ctx* c, int klass, T* X, int64_t mpad, int64_t ldx, co
 // X (npad x npad, holding the identity) <- L^-T (upper triangular; zero parts are never touched)
 template <typename T>
 int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T* L, int64_t ldl, const T* invD);
+template <typename T>
+int trinv_upper_inplace(algp_ctx* c, int klass, T* XL, int64_t npad, int64_t ld, const T* invD);
 // C (lower tiles, npad x npad) <- X X^T for that upper-triangular X
 template <typename T>
 int syrk_upper(algp_ctx* c, int klass, const T* X, int64_t npad, int64_t ldx, T* C, int64_t ldc);
@@ -425,8 +427,8 @@ int trsv_backward(algp_ctx* c, const T* L, int64_t npad, int64_t ldl, const T* i
 
 // row reductions over V^T: ss[j] = sum_r V[j][r]^2 (if ss), dot[j] = sum_r V[j][r]*w[r] (if w)
 template <typename T>
-int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t ncols, const T* w,
-                       T* ss, T* dot);
+int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t ncols, const T* w, T* ss, T* dot,
+                       int64_t tri_c0 = -1);
 
 template <typename T>
 int test_mfma_launch(algp_ctx* c, int* mismatches_dev);

@@ -369,6 +369,54 @@ int trinv_upper(algp_ctx* c, int klass, T* X, int64_t npad, int64_t ldx, const T
     return ALGP_OK;
 }
 
+// The same inverse IN PLACE: XL holds a factor L in its lower triangle (as cholesky_blocked leaves it) and receives
+// X = L^-T in its upper triangle, diagonal tiles included -- the strictly-lower tiles keep L, which the sweep still reads.
+// One n x n buffer instead of two: what lets the MI criterion hold its two pool-wide inverses at config 4's own pool
+// (110 000 sites: 2 x 96.8 GB; the three matrices of the out-of-place form were 290 GB).  Differences from trinv_upper:
+// the tiles on and above the diagonal are prepared here (identity / zero: they hold S's upper half), and the push of a
+// finished 512-column block into the trailing columns is cut by row tile inside the block -- there X's tiles left of the
+// diagonal are L's, so row tile t of the block multiplies from its own diagonal column on.  Readers of the result must
+// skip the strictly-lower tiles (rows_reduce_launch with tri_c0 >= 0).  Reference: agent.py:330-339 takes two pool-wide
+// slogdets per candidate.
+template <typename T>
+__global__ __launch_bounds__(256) void tri_prep_kernel(T* A, int64_t ld) {
+    const int64_t bi = blockIdx.y, bj = blockIdx.x;
+    if (bi > bj) return;
+    T* t = A + bi * NB * ld + bj * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e >> 7, q = e & 127;
+        t[(int64_t)r * ld + q] = (bi == bj && r == q) ? (T)1 : (T)0;
+    }
+}
+template <typename T>
+int trinv_upper_inplace(algp_ctx* c, int klass, T* XL, int64_t npad, int64_t ld, const T* invD) {
+    const unsigned nt = (unsigned)(npad / NB);
+    if (nt > 65535) return fail(c, ALGP_ERR_BAD_ARG, "trinv_upper_inplace: matrix too large");
+    hipLaunchKernelGGL(tri_prep_kernel<T>, dim3(nt, nt), dim3(256), 0, c->cur, XL, ld);
+    ALGP_HIP(hipGetLastError());
+    for (int64_t j0 = 0; j0 < npad; j0 += WB) {
+        const int64_t w = (npad - j0 < WB) ? npad - j0 : WB, j1 = j0 + w;
+        for (int64_t k0 = j0; k0 < j1; k0 += NB) {
+            T* Xk = XL + k0;
+            const int64_t rows = k0 + NB;
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, rows, NB, NB, (T)1, Xk, ld, invD + (k0 / NB) * NB * NB, NB, (T)0, nullptr, 0, Xk, ld, 0));
+            if (k0 + NB < j1)
+                ALGP_TRY(gemm_nt_launch<T>(c, klass, rows, j1 - (k0 + NB), NB, (T)-1, Xk, ld, XL + (k0 + NB) * ld + k0, ld, (T)1,
+                                           Xk + NB, ld, Xk + NB, ld, 0));
+        }
+        if (j1 >= npad) break;
+        // rows above the block: dense in X; rows inside it: from their own diagonal tile on
+        if (j0 > 0)
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, j0, npad - j1, w, (T)-1, XL + j0, ld, XL + j1 * ld + j0, ld, (T)1, XL + j1, ld, XL + j1, ld, 0));
+        for (int64_t r0 = j0; r0 < j1; r0 += NB)
+            ALGP_TRY(gemm_nt_launch<T>(c, klass, NB, npad - j1, j1 - r0, (T)-1, XL + r0 * ld + r0, ld, XL + j1 * ld + r0, ld, (T)1,
+                                       XL + r0 * ld + j1, ld, XL + r0 * ld + j1, ld, 0));
+    }
+    return ALGP_OK;
+}
+template int trinv_upper_inplace<double>(algp_ctx*, int, double*, int64_t, int64_t, const double*);
+template int trinv_upper_inplace<float>(algp_ctx*, int, float*, int64_t, int64_t, const float*);
+
 // C (lower tiles) <- X X^T for the upper-triangular X above: ONE launch in which output tile (a, b <= a) sums over the
 // columns k >= 128 a only (row tile a of X is zero left of them; GemmArgs::ktri).  The tiles are dealt out by ascending a,
 // i.e. longest K first, so the 512 resident workgroups end within one short tile of each other.  (Rounds 1-3: a sum over

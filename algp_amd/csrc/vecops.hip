@@ -44,15 +44,18 @@ __device__ __forceinline__ void wave_row_reduce(const T* row, const T* w, int64_
     }
 }
 
+// tri_c0 >= 0: Vt is UPPER triangular by 128-tiles (row j is zero -- or holds something else: the MI criterion keeps a
+// factor's strictly-lower tiles there -- left of column 128 (j / 128)): row j is walked from max(128 (j / 128), tri_c0) on
 template <typename T, bool HAS_W, bool HAS_SS>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const T* Vt, int64_t rows, int64_t ldv, int64_t ncols,
-                                                          const T* w, T* ss, T* dot) {
+                                                          const T* w, T* ss, T* dot, int64_t tri_c0) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
     for (int64_t j = wave; j < rows; j += nw) {
         T s2, sd;
-        wave_row_reduce<T, HAS_W, HAS_SS>(Vt + j * ldv, w, ncols, lane, s2, sd);
+        const int64_t c0 = tri_c0 < 0 ? 0 : (j / 128 * 128 > tri_c0 ? j / 128 * 128 : tri_c0);
+        wave_row_reduce<T, HAS_W, HAS_SS>(Vt + j * ldv + c0, HAS_W ? w + c0 : w, ncols - c0, lane, s2, sd);
         if (lane == 0) {
             if (HAS_SS) ss[j] = s2;
             if (HAS_W) dot[j] = sd;
@@ -196,20 +199,21 @@ template int combine3_launch<float>(algp_ctx*, int64_t, const float*, const floa
 
 template <typename T>
 int rows_reduce_launch(algp_ctx* c, const T* Vt, int64_t rows, int64_t ldv, int64_t ncols, const T* w, T* ss,
-                       T* dot) {
+                       T* dot, int64_t tri_c0) {
     if (rows <= 0) return ALGP_OK;
     int64_t g = (rows + 3) / 4;
     if (g > 8192) g = 8192;
-    ProfScope ps(c, ALGP_PROF_ROWS, 2.0 * rows * ncols * ((w ? 1 : 0) + (ss ? 1 : 0)), sizeof(T) * (double)rows * ncols);
+    const double share = tri_c0 < 0 ? 1.0 : 0.5;                   // an upper triangle is half the bytes
+    ProfScope ps(c, ALGP_PROF_ROWS, share * 2.0 * rows * ncols * ((w ? 1 : 0) + (ss ? 1 : 0)), share * sizeof(T) * (double)rows * ncols);
     dim3 grid((unsigned)g), blk(256);
-    if (w && ss) hipLaunchKernelGGL((rows_reduce_kernel<T, true, true>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot);
-    else if (w) hipLaunchKernelGGL((rows_reduce_kernel<T, true, false>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot);
-    else if (ss) hipLaunchKernelGGL((rows_reduce_kernel<T, false, true>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot);
+    if (w && ss) hipLaunchKernelGGL((rows_reduce_kernel<T, true, true>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot, tri_c0);
+    else if (w) hipLaunchKernelGGL((rows_reduce_kernel<T, true, false>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot, tri_c0);
+    else if (ss) hipLaunchKernelGGL((rows_reduce_kernel<T, false, true>), grid, blk, 0, c->cur, Vt, rows, ldv, ncols, w, ss, dot, tri_c0);
     ALGP_HIP(hipGetLastError());
     return ALGP_OK;
 }
-template int rows_reduce_launch<double>(algp_ctx*, const double*, int64_t, int64_t, int64_t, const double*, double*, double*);
-template int rows_reduce_launch<float>(algp_ctx*, const float*, int64_t, int64_t, int64_t, const float*, float*, float*);
+template int rows_reduce_launch<double>(algp_ctx*, const double*, int64_t, int64_t, int64_t, const double*, double*, double*, int64_t);
+template int rows_reduce_launch<float>(algp_ctx*, const float*, int64_t, int64_t, int64_t, const float*, float*, float*, int64_t);
 
 // The row statistics the candidate solve left per column tile (gemm.hip, STATS: stat[(2 t + 0 / 1) * ld + row]) summed over
 // the tiles in ascending order: ss = sum v^2, dot = sum v z of every row, without a second pass over V^T.
