@@ -15,6 +15,7 @@
 // without it), a caller-supplied host all-gather (algp_comm_init_host: MPI, gloo, ... -- also what lets two ranks share
 // ONE card in the tests, which RCCL refuses), or none (one rank: the same kernels without the gather).
 #include "common.h"
+#include <mutex>
 #include <algorithm>
 #include <dlfcn.h>
 #include <link.h>
@@ -45,10 +46,15 @@ static int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
     return 0;
 }
 
+// (Loaded once per process, under a lock: two contexts of one process may attach their communicators from two threads at
+// the same time -- the eight-rank tests do -- and the second must not see a half-initialised table.  Round 5's bare flag
+// let it: "comm_init: " with an empty reason on one rank, the others waiting for it in ncclCommInitRank.)
 static RcclApi* rccl_api(std::string* why) {
     static RcclApi api;
     static bool tried = false;
     static std::string err;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (!tried) {
         tried = true;
         std::string loaded;

@@ -241,13 +241,13 @@ def _tail_traffic(alg_bytes):
     there x algorithmic here.  None when the file or the kernel's sources (tail.hip) changed since."""
     import hashlib
     try:
-        tj = json.load(open(os.path.join(REPO, 'profiles', 'r05_traffic_pmc.json')))
+        tj = json.load(open(os.path.join(REPO, 'profiles', 'r06_traffic_pmc.json')))
         sha = hashlib.sha256(open(os.path.join(REPO, 'algp_amd', 'csrc', 'tail.hip'), 'rb').read()).hexdigest()[:16]
         if tj.get('tail_sources_sha16') != sha:
             return None, {'note': 'null: tail.hip changed since the PMC passes', 'tail_sources_sha16_now': sha,
                           'tail_sources_sha16_measured': tj.get('tail_sources_sha16')}
         ratio = tj['tail_part_f64_bytes_per_launch'] / tj['tail_part_f64_algorithmic_bytes_per_launch_same_run']
-        return ratio * alg_bytes, {'source': 'profiles/r05_traffic_pmc.json', 'measured_over_algorithmic': ratio, 'tail_sources_sha16': sha}
+        return ratio * alg_bytes, {'source': 'profiles/r06_traffic_pmc.json', 'measured_over_algorithmic': ratio, 'tail_sources_sha16': sha}
     except Exception as e:
         return None, {'note': 'null: %s' % e}
 
@@ -910,7 +910,7 @@ def main():
     ap.add_argument('--extra-loop-steps', type=int, default=200, help='with --gpus N > 1 the line also carries extra.c5_loop: config 5\'s loop '
                     'for this many incremental steps on the N ranks (0 or --no-extras: skipped)')
     ap.add_argument('--cpu-train', type=int, default=6000)
-    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r05_traffic_pmc.json'))
+    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'r06_traffic_pmc.json'))
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -1128,6 +1128,12 @@ def main():
             if tj.get('sources_sha16') == traffic_info['sources_sha16_now'] and args.train == 10000 and args.cand == 100000 and world == 1:
                 traffic = tj.get('gemm_nt_%s_bytes_per_launch' % args.dtype)
                 traffic_info['bytes_per_solve'] = tj.get('bytes_per_solve_%s' % args.dtype)
+                traffic_info['fetch_factor'] = tj.get('fetch_factor')          # FETCH_SIZE x this = bytes: calibrated, see the source
+                traffic_info['fetch_factor_source'] = tj.get('fetch_factor_source')
+                if traffic_info['bytes_per_solve']:
+                    # algorithmic minimum of a solve: V^T written once + read as the A operand of 20 block columns' updates is
+                    # NOT minimal; the minimum is s * (N^2 / 2 + 2 N M)
+                    traffic_info['over_algorithmic'] = traffic_info['bytes_per_solve'] / ((8 if args.dtype == 'f64' else 4) * (N * N / 2.0 + 2.0 * N * Mloc))
             else:
                 traffic_info['note'] = 'null: the PMC passes were taken on other kernel sources or another workload than this run'
         except Exception as e:

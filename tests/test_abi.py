@@ -92,15 +92,26 @@ def test_bench_self_spawn_command_line(monkeypatch):
 
 
 def test_a_build_without_test_hooks_exports_no_debug_symbol(tmp_path):
-    """`make TEST_HOOKS=0` (-DALGP_TEST_HOOKS=0): the C-ABI translation unit compiled that way (host side only: seconds)
-    defines every product entry point and none of the nine algp_debug_* hooks (include/algp_hip.h, section "test hooks")."""
+    """`make TEST_HOOKS=0` (-DALGP_TEST_HOOKS=0): the C-ABI translation units compiled that way (host side only: seconds each)
+    define every product entry point and none of the nine algp_debug_* hooks (include/algp_hip.h, section "test hooks")."""
     import subprocess
-    obj = tmp_path / 'api_nohooks.o'
     csrc = os.path.join(REPO, 'algp_amd', 'csrc')
-    r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O1', '-std=c++17', '-fPIC', '-DALGP_TEST_HOOKS=0', '-I' + csrc,
-                        '--cuda-host-only', '-c', os.path.join(csrc, 'api.hip'), '-o', str(obj)], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    syms = subprocess.run(['nm', str(obj)], capture_output=True, text=True).stdout
-    defined = set(re.findall(r' T (algp_[a-z0-9_]+)', syms))
+    defined = set()
+    for unit in sorted(f for f in os.listdir(csrc) if f.startswith('api') and f.endswith('.hip')):
+        obj = tmp_path / (unit + '.o')
+        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O1', '-std=c++17', '-fPIC', '-DALGP_TEST_HOOKS=0', '-I' + csrc,
+                            '--cuda-host-only', '-c', os.path.join(csrc, unit), '-o', str(obj)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (unit, r.stderr[-3000:])
+        defined |= set(re.findall(r' T (algp_[a-z0-9_]+)', subprocess.run(['nm', str(obj)], capture_output=True, text=True).stdout))
     assert not [s for s in defined if s.startswith('algp_debug_')], defined
-    assert 'algp_greedy_sharded' in defined and 'algp_fit_and_solve' in defined and len(defined) >= 50
+    decl = [s for s in _declared_symbols() if not s.startswith('algp_debug_')]
+    assert sorted(defined) == decl, set(decl) ^ defined
+
+
+def test_the_library_exports_the_c_abi_and_nothing_else():
+    """csrc/exports.map: the dynamic symbol table holds the entry points of include/algp_hip.h only -- no C++ launcher, no
+    template instantiation leaks out of the .so."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _hip.LIB_PATH], capture_output=True, text=True).stdout
+    names = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert names == _declared_symbols(), set(names) ^ set(_declared_symbols())

@@ -374,8 +374,10 @@ def _spawn(tmp_path, text, args_of, n, env, token):
         for p in procs:                                        # exactly the processes started here
             if p.poll() is None:
                 p.kill()
+    failed = ['process %d (rc %s):\n%s\n%s' % (r, p.returncode, so[-2500:], se[-2500:]) for r, (p, (so, se)) in enumerate(zip(procs, outs))
+              if p.returncode != 0]
+    assert not failed, '\n'.join(failed)
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, 'process %d:\n%s\n%s' % (r, so[-3000:], se[-5000:])
         assert token % r in so, so[-2000:]
 
 

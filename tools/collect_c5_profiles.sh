@@ -4,7 +4,7 @@
 # timeline, the folded rank step of config 4 with its MFMA-busy counters, the tail kernel by width, the fold's task breakdown.
 #   bash tools/collect_c5_profiles.sh OUTDIR
 set -e -o pipefail
-OUT=${1:-gpurun_out/prof_r05_c5}
+OUT=${1:-gpurun_out/prof_r06_c5}
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
 R=$PWD

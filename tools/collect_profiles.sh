@@ -7,7 +7,7 @@
 #   bash tools/collect_profiles.sh f64|f32 OUTDIR [TRAFFIC_JSON]      (on the GPU box; OUTDIR under gpurun_out/)
 set -e -o pipefail
 DT=${1:-f64}
-OUT=${2:-gpurun_out/prof_r05_$DT}
+OUT=${2:-gpurun_out/prof_r06_$DT}
 TRAFFIC=${3:-$OUT/traffic_pmc.json}
 ARGS="bench.py --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-emulation --traffic-json $TRAFFIC"
 mkdir -p $OUT $(dirname $TRAFFIC)

@@ -97,9 +97,12 @@ typedef const __attribute__((address_space(1))) void* glb_vp;
 
 // ---- 128 x 128 tile product acc += A B^T, A and B row-major with k contiguous: the four-stage LDS-DMA
 // pipeline of gemm.hip (three 64-byte k-tiles in flight while one is multiplied) as a device routine ----
+// draw_ctrl != nullptr: three k-tiles before the end (about 6 us of products) lane 0 of wave 0 draws the workgroup's next
+// ticket from draw_ctrl[0] -- the atomic is one more returning operation in the DMA's in-order queue, so the hand-placed
+// vmcnt waits only get stricter, and the last tile's vmcnt(0) has it back: *nxt is valid in lane 0 of wave 0 behind the loop.
 template <typename T>
 __device__ __forceinline__ void tile_mainloop(char* smem, const T* A0, int64_t lda, const T* B0, int64_t ldb, int nkt,
-                                              typename MF<T>::acc_t (&acc)[4][4]) {
+                                              typename MF<T>::acc_t (&acc)[4][4], int* draw_ctrl = nullptr, int* nxt = nullptr) {
     using F = MF<T>;
     using chunk_t = typename F::chunk_t;
     constexpr int EPC = F::EPC;
@@ -155,11 +158,13 @@ __device__ __forceinline__ void tile_mainloop(char* smem, const T* A0, int64_t l
         asm volatile("" ::: "memory");
     };
     int st = 0;
+    const int kdraw = nkt > 3 ? nkt - 3 : 0;
     for (int kt = 0; kt < nkt; ++kt) {
         arrive(nkt - 1 - kt);
         chunk_t a[4], b[4];
         fread(st, a, b);
         if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, kt + NST - 1);
+        if (draw_ctrl && kt == kdraw && tid == 0) *nxt = atomicAdd(&draw_ctrl[0], 1);
         fmac(a, b);
         st = (st + 1 == NST) ? 0 : st + 1;
     }
@@ -212,6 +217,35 @@ __device__ __forceinline__ T* dag_row(const DagArgs<T>& g, int i, int64_t& ldr) 
     ldr = g.ldp;
     return g.P + (int64_t)(i - g.nt) * 128 * g.ldp;
 }
+// The FIRST wait of a task as (address, target) per lane of wave 0 (nullptr: nothing to wait for in this lane).
+template <typename T>
+__device__ __forceinline__ const int* dag_first_wait(const DagArgs<T>& g, const DagTask& task, int lane, int& want) {
+    const int type = task.type, ti = task.i, tj = task.j, k0 = task.kk >> 16, k1 = task.kk & 0xffff;
+    if (type == DAG_TU) {                                      // tile (i,k) updated k times; diagonal block k factored
+        want = lane == 0 ? tj : tj + 1;
+        return lane == 0 ? dag_ver(g, ti, tj) : (lane == 1 ? dag_ver(g, tj, tj) : nullptr);
+    }
+    int ndeps, di = ti, dj = tj;
+    want = 0;
+    if (type == DAG_TRSM) {
+        ndeps = 2;
+        if (lane == 0) want = tj;                              // tile (i,k) updated k times
+        else { di = tj; dj = tj; want = tj + 1; }              // diagonal block k factored
+    } else {
+        const int n = k1 - k0;
+        ndeps = 1 + (ti == tj ? n : 2 * n);
+        if (lane == 0) want = k0;
+        else if (lane <= n) { dj = k0 + lane - 1; want = dj + 1; }
+        else { di = tj; dj = k0 + lane - n - 1; want = dj + 1; }
+    }
+    return lane < ndeps ? dag_ver(g, di, dj) : nullptr;
+}
+// What a bulk workgroup knows about its NEXT task while it finishes the current one (in LDS): the ticket, the task, and
+// whether its first wait was already satisfied -- and the acquire issued -- before the current tile's stores.
+struct DagNext {
+    int ticket, pre_ok;
+    DagTask task;
+};
 // Publish tile (i, j) at version `ver`: every wave's (write-through) stores drained, barrier, version store.
 template <typename T>
 __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, int ver) {
@@ -229,8 +263,17 @@ __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, i
     }
 }
 // UPD: tile (i, j) -= L_i,[k0,k1) L_j,[k0,k1)^T.  TRSM (upd == false): tile (i, j) <- tile (i, j) X_jj^T, in place.
+// nx != nullptr (round 6): the workgroup's NEXT ticket is drawn three k-tiles before the end of the product (tile_mainloop);
+// behind the product wave 0 fetches that task, polls its first wait once and, if the inputs are there already (the rule for
+// far updates), issues the acquire -- all of it before the tile's stores, whose 3-4 us of issue and drain cover the
+// invalidate.  Round 5's stamps had 2.3 us between a publish and the next ticket and 4.1 us from the ticket to "inputs seen";
+// both are gone for a task whose inputs were ready.  Tickets are still handed out in list order and a workgroup holds at
+// most one beyond the task it executes (for ~6 us), so the replay argument stands: the smallest unfinished ticket is always
+// being executed (tools/dag_sched_probe.hip).  An acquire that precedes the stores is as good as one behind them: every
+// later load of this CU sees memory at least as new as when the versions were read.
 template <typename T>
-__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1) {
+__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1,
+                                            DagNext* nx = nullptr) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     const int lane = threadIdx.x & 63, fr = lane & 15;
@@ -272,8 +315,28 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
         nkt = 128 / (4 * F::EPC);
     }
     DAG_PHASE(ph1);
-    tile_mainloop<T>(smem, A0, ldr, B0, ldb, nkt, acc);
+    int nxt = 0;
+    tile_mainloop<T>(smem, A0, ldr, B0, ldb, nkt, acc, nx ? g.ctrl : nullptr, &nxt);
     DAG_PHASE(ph2);
+    if (nx && wave == 0) {                                     // (a wave-uniform branch)
+        const int n = __builtin_amdgcn_readfirstlane(nxt);
+        DagTask nt_ = {0, 0, 0, 0};
+        bool ok = false;
+        if (n < g.ntasks) {
+            nt_ = g.tasks[n];
+            int want;
+            const int* a = dag_first_wait<T>(g, nt_, lane, want);
+            const bool mine = a != nullptr;
+            const int v = __hip_atomic_load(mine ? a : g.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = __all(!mine || v >= want);
+            if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (lane == 0) {
+            nx->ticket = n;
+            nx->pre_ok = ok ? 1 : 0;
+            nx->task = nt_;
+        }
+    }
     const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -511,23 +574,43 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     // ---- everybody else draws tickets from the list ----
     unsigned long long st_upd = 0, st_trsm = 0;
     unsigned st_steps = 0, st_ntrsm = 0;
-    for (;;) {
-        if (tid < 64) {
-            // a workgroup that shares its CU with a team member retires
-            bool beside = lane < DAG_TEAM && __hip_atomic_load(&g.ctrl[8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
-            beside = __any(beside);
-            if (tid == 0) s_ticket = beside ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
+    // A workgroup that shares its CU with a team member retires at once.  The team's CUs are known once its DAG_TEAM
+    // members have registered (they arrived before this workgroup and do so first thing): wait for that, a bounded wait.
+    __shared__ DagNext s_nx;
+    if (tid < 64) {
+        bool beside = false;
+        if (!g.no_team) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const int key = lane < DAG_TEAM ? __hip_atomic_load(&g.ctrl[8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+                if (__all(key != 0)) { beside = __any(lane < DAG_TEAM && key == cu_key); break; }
+                if (__hip_atomic_load(&g.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                    __builtin_amdgcn_s_memrealtime() - t_start > g.spin_limit) { beside = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
         }
+        if (tid == 0) {
+            s_nx.ticket = beside ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
+            s_nx.pre_ok = 0;
+            s_nx.task.type = -1;                               // the first task comes from the list in global memory
+        }
+    }
+    for (;;) {
+        // ticket, task and "inputs seen" of this iteration were left in s_nx inside the previous task (dag_tile_op), or above
         __syncthreads();                                       // also: every wave is done with the previous task's LDS
         // wave-uniform in fact, and told so to the compiler: with a (formally) divergent loop exit hipcc lets the
         // lanes that stay in the loop run ahead into the next iteration's barrier before lane 0 has published
-        const int t = __builtin_amdgcn_readfirstlane(s_ticket);
+        const int t = __builtin_amdgcn_readfirstlane(s_nx.ticket);
+        const bool pre_ok = __builtin_amdgcn_readfirstlane(s_nx.pre_ok) != 0;
+        const bool task_here = __builtin_amdgcn_readfirstlane(s_nx.task.type) >= 0;
         DAG_DBG(0, t);
         DAG_DBG(1, 1);
         if (t >= g.ntasks) break;
         DAG_TRACE(t, 0);
         DAG_WHO(t);
-        const DagTask task = g.tasks[t];
+        DagTask task;
+        if (task_here) task = s_nx.task;
+        else task = g.tasks[t];
         const int type = task.type, ti = task.i, tj = task.j, k0 = task.kk >> 16, k1 = task.kk & 0xffff;
 
         if (type == DAG_TU) {
@@ -536,8 +619,11 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
             // was the longest path of the whole graph (76 x 78 us for the last row); one workgroup does both, the
             // second product reading the tile it has just written.
             const int k = tj;
-            if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k) : (lane == 1 ? dag_ver(g, k, k) : nullptr),
-                             lane == 0 ? k : k + 1, &s_ok)) break;
+            if (!pre_ok) {
+                int want1;
+                const int* a1 = dag_first_wait<T>(g, task, lane, want1);
+                if (!dag_wait<T>(g, t, a1, want1, &s_ok)) break;
+            }
             DAG_TRACE(t, 1);
             unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
             dag_tile_op<T>(g, sm.gemm, false, ti, k, k, k + 1);
@@ -547,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
             if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k + 1) : (lane == 1 ? dag_ver(g, k + 1, k) : nullptr),
                              lane == 0 ? k : k + 1, &s_ok)) break;
             tick0 = __builtin_amdgcn_s_memrealtime();
-            dag_tile_op<T>(g, sm.gemm, true, ti, k + 1, k, k + 1);
+            dag_tile_op<T>(g, sm.gemm, true, ti, k + 1, k, k + 1, &s_nx);
             st_upd += __builtin_amdgcn_s_memrealtime() - tick0;
             ++st_steps;
             DAG_TRACE(t, 2);
@@ -555,24 +641,16 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
             DAG_TRACE(t, 3);
             continue;
         }
-        // ---- wait for the inputs: lane l polls dependency l ----
-        int ndeps, di = ti, dj = tj, want = 0;
-        if (type == DAG_TRSM) {
-            ndeps = 2;
-            if (lane == 0) want = tj;                          // tile (i,k) updated k times
-            else { di = tj; dj = tj; want = tj + 1; }          // diagonal block k factored
-        } else {
-            const int n = k1 - k0;
-            ndeps = 1 + (ti == tj ? n : 2 * n);
-            if (lane == 0) want = k0;
-            else if (lane <= n) { dj = k0 + lane - 1; want = dj + 1; }
-            else { di = tj; dj = k0 + lane - n - 1; want = dj + 1; }
+        // ---- wait for the inputs (lane l polls dependency l) unless they were seen, and acquired, inside the previous task ----
+        if (!pre_ok) {
+            int want1;
+            const int* a1 = dag_first_wait<T>(g, task, lane, want1);
+            if (!dag_wait<T>(g, t, a1, want1, &s_ok)) break;
         }
-        if (!dag_wait<T>(g, t, lane < ndeps ? dag_ver(g, di, dj) : nullptr, want, &s_ok)) break;
         DAG_DBG(1, 2);
         DAG_TRACE(t, 1);
         const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
-        dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1);
+        dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1, &s_nx);
         const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - tick0;
         if (type == DAG_UPD) { st_upd += ticks; st_steps += (unsigned)(k1 - k0); }
         else { st_trsm += ticks; ++st_ntrsm; }

@@ -229,8 +229,14 @@ __device__ __forceinline__ void dag_publish(const DagArgs<T>& g, int i, int j, i
     }
 }
 // UPD: tile (i, j) -= L_i,[k0,k1) L_j,[k0,k1)^T.  TRSM (upd == false): tile (i, j) <- tile (i, j) X_jj^T, in place.
+// s_next != nullptr: the workgroup's NEXT ticket is drawn here, between the last product and the tile's stores (round 6): the
+// atomic's round trip (2.3 us between a publish and the next ticket in round 5's stamps) runs under the 3-4 us the 64 stores
+// of a lane take to issue and drain; the value lands in *s_next behind the stores, the publish's barrier makes it visible.
+// Tickets are still handed out in list order and a workgroup holds at most one beyond the task it executes, so the
+// replay argument stands (the smallest unfinished ticket is always being executed: tools/dag_sched_probe.hip).
 template <typename T>
-__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1) {
+__device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, bool upd, int ti, int tj, int k0, int k1,
+                                            int* s_next = nullptr, int cu_key = 0) {
     using F = MF<T>;
     using acc_t = typename F::acc_t;
     const int lane = threadIdx.x & 63, fr = lane & 15;
@@ -274,6 +280,13 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
     DAG_PHASE(ph1);
     tile_mainloop<T>(smem, A0, ldr, B0, ldb, nkt, acc);
     DAG_PHASE(ph2);
+    int nxt = 0;
+    if (s_next && threadIdx.x < 64) {                          // (wave 0: a wave-uniform branch)
+        // a workgroup that shares its CU with a team member retires instead of drawing
+        bool beside = lane < DAG_TEAM && __hip_atomic_load(&g.ctrl[8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
+        beside = __any(beside);
+        if (threadIdx.x == 0) nxt = beside ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
+    }
     const T sgn = upd ? (T)-1 : (T)1;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -283,6 +296,7 @@ __device__ __forceinline__ void dag_tile_op(const DagArgs<T>& g, char* smem, boo
 #pragma unroll
             for (int j = 0; j < 4; ++j) st_wt(&Cij[gi * ldr + wc * 64 + j * 16 + fr], sgn * acc[i][j][r]);
         }
+    if (s_next && threadIdx.x == 0) *s_next = nxt;
 #ifdef ALGP_DAG_DEBUG
     // Where a K = 128 product spends its time (tools/dag_test.hip prints the means): "issuing" the 64 loads / 64 stores
     // of a lane takes 3-5 us each, and that is the memory system's back-pressure, not the instruction count -- with
@@ -511,13 +525,14 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
     // ---- everybody else draws tickets from the list ----
     unsigned long long st_upd = 0, st_trsm = 0;
     unsigned st_steps = 0, st_ntrsm = 0;
+    if (tid < 64) {
+        // a workgroup that shares its CU with a team member retires
+        bool beside = lane < DAG_TEAM && __hip_atomic_load(&g.ctrl[8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
+        beside = __any(beside);
+        if (tid == 0) s_ticket = beside ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
+    }
     for (;;) {
-        if (tid < 64) {
-            // a workgroup that shares its CU with a team member retires
-            bool beside = lane < DAG_TEAM && __hip_atomic_load(&g.ctrl[8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cu_key;
-            beside = __any(beside);
-            if (tid == 0) s_ticket = beside ? 0x7fffffff : atomicAdd(&g.ctrl[0], 1);
-        }
+        // the ticket was drawn inside the previous task (dag_tile_op, before its stores), or above for the first
         __syncthreads();                                       // also: every wave is done with the previous task's LDS
         // wave-uniform in fact, and told so to the compiler: with a (formally) divergent loop exit hipcc lets the
         // lanes that stay in the loop run ahead into the next iteration's barrier before lane 0 has published
@@ -547,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
             if (!dag_wait<T>(g, t, lane == 0 ? dag_ver(g, ti, k + 1) : (lane == 1 ? dag_ver(g, k + 1, k) : nullptr),
                              lane == 0 ? k : k + 1, &s_ok)) break;
             tick0 = __builtin_amdgcn_s_memrealtime();
-            dag_tile_op<T>(g, sm.gemm, true, ti, k + 1, k, k + 1);
+            dag_tile_op<T>(g, sm.gemm, true, ti, k + 1, k, k + 1, &s_ticket, cu_key);
             st_upd += __builtin_amdgcn_s_memrealtime() - tick0;
             ++st_steps;
             DAG_TRACE(t, 2);
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(DagArgs<T> g) {
         DAG_DBG(1, 2);
         DAG_TRACE(t, 1);
         const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
-        dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1);
+        dag_tile_op<T>(g, sm.gemm, type == DAG_UPD, ti, tj, k0, k1, &s_ticket, cu_key);
         const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - tick0;
         if (type == DAG_UPD) { st_upd += ticks; st_steps += (unsigned)(k1 - k0); }
         else { st_trsm += ticks; ++st_ntrsm; }

@@ -18,8 +18,12 @@ spec.loader.exec_module(bench)
 out = {'sources_sha16': bench.sources_sha16(),
        'commit': subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=REPO, capture_output=True, text=True).stdout.strip() or None,
        'command': 'bench.py --dtype <dt> --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-emulation (7 candidate solves per run: 1 warm-up + 3 timed with the stage timers + 3 without)',
+       'fetch_factor': 2.0,
+       'fetch_factor_source': 'profiles/r06_fetch_calibration.txt (tools/fetch_calibrate.sh): FETCH_SIZE x 2 = the true byte count to 0.1 % for '
+                              '64 / 128 / 256 / 1024-byte row pieces, plain loads and LDS-DMA, all three lane orders of the GEMM\'s 64-byte pieces',
        'note': 'bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): gfx950 tallies the 128-byte requests of wide streaming reads at 64 '
-               'bytes (MI355X_MICROARCH.md, HBM); separate --pmc passes; FETCH/WRITE count the L2\'s fabric-side requests, so '
+               'bytes (MI355X_MICROARCH.md, HBM; calibrated for this library\'s request patterns in round 6, see fetch_factor_source); '
+               'separate --pmc passes; FETCH/WRITE count the L2\'s fabric-side requests, so '
                'Infinity-Cache hits are included.  WRITE_SIZE is calibrated for 16-byte-per-lane streaming stores; the Cholesky\'s '
                'tile stores are 8-byte (fp64) / 4-byte (fp32) write-through stores, its write figure is uncalibrated.'}
 for dt, path in (('f64', sys.argv[1]), ('f32', sys.argv[2])):

@@ -4,7 +4,8 @@ usage: python tools/pmc_summary.py <out.json> <stats_dir> <pmc_dir> [<pmc_dir> .
   stats_dir : a `rocprofv3 --kernel-trace --stats` run of the same command (per-symbol calls / average duration)
   pmc_dir   : runs with --pmc (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE), in own passes
 Derived per symbol (MI355X_MICROARCH.md): MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs);
-HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B requests of wide streaming reads at 64 B) + WRITE_SIZE, both in KiB;
+HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated in round 6 against known byte counts in this library's own
+request patterns -- 64 / 128 / 256 / 1024-byte row pieces, plain and LDS-DMA: 2.000 each, profiles/r06_fetch_calibration.txt) + WRITE_SIZE, both in KiB;
 GB/s = bytes / the launches' own durations in the counter pass (counter passes serialise dispatches that overlap on several
 streams in the stats run)."""
 import csv

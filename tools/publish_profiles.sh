@@ -2,7 +2,7 @@
 # copies what tools/collect_profiles.sh (both dtypes) and tools/collect_c5_profiles.sh left under gpurun_out/ into profiles/
 # under this round's names (gpurun_out/ is scratch; profiles/ is what is committed):  bash tools/publish_profiles.sh r05
 set -e
-R=${1:-r05}
+R=${1:-r06}
 G=gpurun_out
 for DT in f64 f32; do
   D=$G/prof_${R}_$DT
