@@ -1059,7 +1059,7 @@ def main():
         # step -- pool coordinates, train set and candidate list up (H2D inside the calls), the picks back on the host -- where
         # the headline's steps start from resident inputs (reference utils.py:293-319 is host-in / host-out)
         host_ms = []
-        if world == 1:
+        if world == 1 and not args.no_emulation:                  # (profiling runs, --no-emulation, hold only the workload's own 7 solves)
             picks_resident = picks_log[-1]
             for _ in range(max(3, min(args.steps, 10))):
                 barrier()
