@@ -343,7 +343,7 @@ def test_mi_criterion_at_5000_sites_matches_oracle():
 @pytest.mark.parametrize('dtname', ['f64', 'f32'])
 def test_mi_criterion_rank1_updates_follow_the_oracle_pick_by_pick(dtname):
     """Picks 2..k of the MI criterion fold the previous winner into the two resident inverse diagonals (O(n^2) rank-1
-    updates, api.hip mi_apply_pick) where the reference and the oracle refactorise two pool-wide matrices per pick
+    updates, api_greedy.hip mi_apply_pick) where the reference and the oracle refactorise two pool-wide matrices per pick
     (agent.py:330-339): every utility of 6 forced picks against the oracle's from-scratch terms -- new sites AND
     mobile-sampled sites among the picks (the latter change the noise of a site that stays outside the complement)."""
     dt = np.float64 if dtname == 'f64' else np.float32
