@@ -196,11 +196,12 @@ int Impl<T>::exchange_new_rows(algp_ctx* c, int64_t Nb, int64_t p0, int* placed,
     }
     const size_t rowbytes = sizeof(T) * (size_t)Nb;
     // sized by the factor's capacity, not by this step's Nb and cap: the buffers then stay put while the train set grows
-    if (st <= 1 && cap > 0) {
+    // (a rank that takes part only to say "I keep nothing" reserves nothing: its plan would cover the whole train set)
+    if (st <= 1 && cap > 0 && Nb > 0) {
         const int rc = comm_rows_reserve(c, sizeof(T) * (size_t)c->Lld * (size_t)std::max<int64_t>(16, round_up(cap, 8)));
         if (rc != ALGP_OK) st = rc;
     }
-    if (st <= 1) {
+    if (st <= 1 && Nb > 0) {
         int rc = ensure(c, c->auxIdx, sizeof(int64_t) * 2 * (size_t)std::max<int64_t>(std::max(ntot, cap), 1));
         if (rc == ALGP_OK) rc = ensure(c, c->auxVar, sizeof(T) * (size_t)std::max<int64_t>(cap, 1) + 256);
         if (rc != ALGP_OK) st = rc;
