@@ -340,6 +340,45 @@ def test_mi_criterion_at_5000_sites_matches_oracle():
     c.close()
 
 
+@pytest.mark.parametrize('R,Cc,nA', [(10, 12, 30), (25, 26, 120), (30, 40, 200), (45, 50, 300)],
+                         ids=['n120_one_tile', 'n650_one_block_and_a_tile', 'n1200_two_blocks_and_a_remainder', 'n2250_four_blocks_ragged'])
+def test_mi_criterion_in_place_inverses_at_ragged_sizes(R, Cc, nA):
+    """Round 6: each of the MI criterion's pool-wide inverses is the triangle X = L^-T written over its own factor
+    (potrf.hip: trinv_upper_inplace; the row reductions walk the triangle only).  Pools whose padded size is one tile, one
+    512-column block + a tile, several blocks + a remainder: the first pick's utilities AND two further picks (each a
+    column S^-1 e_c = X (X^T e_c) of both inverses) against the fp64 oracle, agent.py:330-339."""
+    rng = np.random.RandomState(R * 100 + Cc)
+    grid, _ = O.generate_gaussian_data(R, Cc, k=5, rng=rng)
+    X = grid.astype(np.float64)
+    n = len(X)
+    hyp = O.Hypers(np.log([1.5, 1.5]), 0.0, np.log(1e-2))
+    perm = rng.permutation(n)
+    static = np.zeros(n, bool)
+    mobile = np.zeros(n, bool)
+    static[perm[:nA // 2]] = True
+    mobile[perm[nA // 3:nA]] = True
+    A = np.where(static | mobile)[0]
+    var = np.where(static[A] & mobile[A], 1.0 / (1.0 / 0.01 + 1.0), np.where(static[A], 0.01, 1.0))
+    Cm = O.kernel_matrix(hyp, X) + hyp.noise * np.eye(n)
+    picks, ut = O.greedy_fast(Cm, static, mobile, 0.1, 1.0, 3, 'mutual_information')
+    c = _hip.Context(np.float64)
+    c.set_hypers(hyp.log_lengthscale, hyp.log_outputscale, hyp.log_noise)
+    c.set_pool(X)
+    c.set_train(A, np.zeros(len(A)), var)
+    c.factorize()
+    cand = np.where(~static)[0]
+    c.set_candidates(cand, prior_includes_noise=True)
+    c.solve_candidates()
+    got, gut = c.greedy(_hip.CRIT_MUTUAL_INFORMATION, 0.1, 1.0, 3, forced_picks=[int(q) for q in picks], want_utilities=True)
+    for k in range(3):
+        want = ut[k][cand]
+        fin = np.isfinite(want)
+        assert np.array_equal(fin, np.isfinite(gut[k]))
+        scale = np.max(np.abs(want[fin]))
+        assert np.max(np.abs(gut[k][fin] - want[fin])) <= 1e-7 * scale, (k, np.max(np.abs(gut[k][fin] - want[fin])), scale)
+    c.close()
+
+
 @pytest.mark.parametrize('dtname', ['f64', 'f32'])
 def test_mi_criterion_rank1_updates_follow_the_oracle_pick_by_pick(dtname):
     """Picks 2..k of the MI criterion fold the previous winner into the two resident inverse diagonals (O(n^2) rank-1
