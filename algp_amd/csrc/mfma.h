@@ -2,8 +2,12 @@
 //   fp64: v_mfma_f64_16x16x4_f64   C/D: row = (lane>>4) + 4*reg, col = lane&15
 //   fp32: v_mfma_f32_16x16x4_f32   C/D: row = (lane>>4)*4 + reg, col = lane&15
 // A operand: one scalar per lane, A[i = lane&15][k = lane>>4]; B: B[k = lane>>4][j = lane&15].
-// Accumulators must live in arch VGPRs for fp64 (AGPR accumulators run at half rate, see
-// profiles/r01_mfma_rate_microbench.txt): keep kernels at <= 256 registers.
+// Accumulators: keep kernels at <= 256 registers so that they stay in arch VGPRs.  Not because AccVGPR accumulators are
+// slow -- rocBLAS's fp64 kernel holds 256 of them at 97 % of peak -- but because hipcc does not keep them there in place:
+// round 1's microbenchmark ("AGPR accumulators run at half rate", profiles/r01_mfma_rate_microbench.txt) measured hipcc's
+// own 128 v_accvgpr_write + 128 v_accvgpr_read per 16 MFMAs, and round 6's 256-accumulator kernel got 224-500 copies per
+// k-tile (EXPERIMENTS.md).  Where hipcc does put a small kernel's accumulators into AccVGPRs without copies in the loop
+// (tail_finish_kernel: 64 AGPRs, a 65-us epilogue kernel), that is fine.
 #pragma once
 #include <hip/hip_runtime.h>
 
