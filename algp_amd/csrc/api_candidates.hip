@@ -187,8 +187,21 @@ int Impl<T>::solve_run(algp_ctx* c, typename Impl<T>::SolvePlan& pl) {
         const bool stats_on = env_switch("ALGP_ROW_STATS", true);                                  // read per call: tests flip it
         if (stats_on && keep == 0 && !pl.carried_sums && ensure(c, c->rowstat, sizeof(T) * 2 * (size_t)(Npad / NB) * (size_t)Mpad) == ALGP_OK)
             stat = p(c->rowstat);
-        trc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), Npad, c->Lld, p(c->invD), keep, p(c->z), stat,
-                              Mpad, &pl.rowstat_done);
+        // A train set that ends a few columns into its last 128-column tile (N = 10 000: 16 of 128) pays the sweep's full price
+        // for that tile -- 2 M 128 N flop, 2.1 % of config 4's solve, for 16 columns.  Up to 64 such columns are instead what an
+        // APPEND would add to a factor of N - r rows: the sweep solves the full tiles, the tail kernel (tail.hip, HBM-bound:
+        // one pass over V^T) the rest, and one 128-column reduction leaves the last tile's row statistics where the sweep's
+        // launches would have (round 6; $ALGP_TAIL_COLS=0: the sweep alone).
+        const int64_t r = c->N % NB, N1 = Npad - NB;
+        const bool narrow = keep == 0 && r > 0 && r <= 64 && N1 >= 2048 && Mpad >= 2048 && c->cur == c->stream &&
+                            Mpad / NB > 320 && env_switch("ALGP_TAIL_COLS", true);      // (320 tile rows: where the chunked sweep begins, potrf.hip)
+        trc = trsm_blocked<T>(c, ALGP_PROF_GEMM_TRSM, p(c->Vt), Mpad, ldc, p(c->L), narrow ? N1 : Npad, c->Lld, p(c->invD), keep, p(c->z),
+                              stat, Mpad, &pl.rowstat_done);
+        if (narrow && trc == ALGP_OK)
+            trc = tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad, p(c->invD) + (N1 / NB) * NB * NB, N1,
+                                      (int)round_up(r, 16));
+        if (narrow && trc == ALGP_OK && pl.rowstat_done)
+            trc = rows_reduce_launch<T>(c, p(c->Vt) + N1, Mpad, ldc, NB, p(c->z) + N1, stat + 2 * (N1 / NB) * Mpad, stat + (2 * (N1 / NB) + 1) * Mpad);
     }
     prof_span_end(c);
     return trc;

@@ -261,7 +261,8 @@ void prof_span_end2(algp_ctx* c);
 
 // ---- environment switches: ALL of them, read through these two functions ------------------------------------------------
 // Size-range fall-backs that are product paths for other sizes, each forced by its switch so that the tests can run both on
-// one input:   ALGP_TAIL_COLS=0 (appended columns re-solved as whole 128-column blocks: what inputs below 2 048 rows take),
+// one input:   ALGP_TAIL_COLS=0 (appended columns re-solved as whole 128-column blocks: what inputs below 2 048 rows take;
+//   also: a from-scratch solve's narrow last tile goes through the sweep instead of the tail kernel),
 //   ALGP_TAIL_SPLIT=0 (the tail kernel without its k-split), ALGP_SOLVE_DAG=0 (mid-sized solves as the right-looking push
 //   instead of the task list), ALGP_FOLD=0 (fit and solve as two steps: what a candidate set beyond 51 200 rows takes),
 //   ALGP_ROW_STATS=0 / ALGP_TRSM_INV512=0 (the chunked solve with a variance pass / with 128-column steps inside a block),

@@ -16,8 +16,7 @@ HYP = O.Hypers(np.log([3.0, 3.0]), 0.0, np.log(1e-2))
 N = 1400                                   # train rows: 11 tiles of 128, the last one ragged
 
 
-def _setup(dtype, M, rng):
-    side = 40
+def _setup(dtype, M, rng, side=40):
     xx, yy = np.meshgrid(np.arange(side), np.arange(side))
     grid = np.vstack([yy.ravel(), xx.ravel()]).T.astype(np.float64)
     A = np.sort(rng.permutation(len(grid))[:N])
@@ -194,6 +193,49 @@ def test_push_order_six_blocks_deep_against_the_oracle_and_itself(monkeypatch):
         assert np.max(np.abs(mu2[samp] - ref['mu'])) <= 1e-9 * max(1.0, np.max(np.abs(ref['mu'])))
         assert np.max(np.abs(pv2[samp] - ref['var'])) <= 1e-9
         assert np.max(np.abs(mu2 - mu_dag)) <= 2e-11 and np.max(np.abs(pv2 - pv_dag)) <= 2e-11
+        c.close()
+    finally:
+        N = old_n
+
+
+@pytest.mark.parametrize('n_train', [2064, 2100, 2112, 2113], ids=['r16', 'r52', 'r64', 'r65_not_narrow'])
+def test_a_narrow_last_tile_is_solved_by_the_tail_kernel(monkeypatch, n_train):
+    """Round 6: a train set that ends r <= 64 columns into its last 128-column tile (config 4: N = 10 000, r = 16) has those
+    columns solved by the tail kernel -- as an append to a factor of N - r rows would -- and the full tiles by the chunked
+    sweep, whose launches no longer pay a whole tile for them; the last tile's row statistics come from a 128-column
+    reduction.  Against the oracle's posterior (utils.py:293-319) on sampled candidates and against the sweep alone
+    ($ALGP_TAIL_COLS=0), for r = 16, 52, 64 and -- unchanged path -- 65."""
+    global N
+    rng = np.random.RandomState(n_train)
+    old_n = N
+    N = n_train
+    try:
+        M = 51300                                                  # > 400 tile rows: beyond the task list, the chunked left-looking sweep
+        c, pool, A, y, var, cidx = _setup(np.float64, M, rng, side=50)
+        c.set_candidates(cidx, prior_includes_noise=False)
+        c.prof_enable(True)
+        c.prof_reset()
+        c.solve_candidates()
+        tail_launches = c.prof_get('tail_cols')['launches']
+        c.prof_enable(False)
+        assert tail_launches == (1 if n_train % 128 <= 64 else 0), tail_launches
+        mu, pv = c.posterior()
+        samp = np.sort(rng.permutation(M)[:160])
+        ref = O.posterior_chol(HYP, pool[A], y, pool[cidx[samp]], var)
+        assert np.max(np.abs(mu[samp] - ref['mu'])) <= 1e-9 * max(1.0, np.max(np.abs(ref['mu'])))
+        assert np.max(np.abs(pv[samp] - ref['var'])) <= 1e-9
+        monkeypatch.setenv('ALGP_TAIL_COLS', '0')
+        c.solve_candidates()
+        mu0, pv0 = c.posterior()
+        assert np.max(np.abs(mu - mu0)) <= 2e-11 and np.max(np.abs(pv - pv0)) <= 2e-11
+        # the rows themselves: greedy picks (which read V^T, not only its sums) agree between the two routes
+        c.set_candidates(cidx, prior_includes_noise=True)
+        c.solve_candidates()
+        p0 = [int(q) for q in c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)]
+        monkeypatch.delenv('ALGP_TAIL_COLS')
+        c.solve_candidates()
+        p1 = [int(q) for q in c.greedy(_hip.CRIT_ENTROPY, 0.1, 1.0, 3)]
+        assert p0 == p1
         c.close()
     finally:
         N = old_n
