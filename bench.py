@@ -1282,7 +1282,10 @@ def main():
                 print(json.dumps(out))
                 sys.stdout.flush()
             # a process that has touched the GPU and is abandoned mid-collective did NOT succeed: non-zero on every
-            # rank; self_spawn relays the line and this code
+            # rank; self_spawn relays the line and this code.  Rank 0 leaves first: the launcher ends every rank as soon as one
+            # has failed, and the line must be out by then.
+            if rank != 0:
+                time.sleep(5.0)
             os._exit(WATCHDOG_EXIT)
         threading.Thread(target=watchdog, daemon=True).start()
         largs = argparse.Namespace(**vars(args))
