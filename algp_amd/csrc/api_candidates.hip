@@ -178,9 +178,19 @@ int Impl<T>::solve_run(algp_ctx* c, typename Impl<T>::SolvePlan& pl) {
         for (int q = 0; q < pl.nseg && trc == ALGP_OK; ++q)
             trc = tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), Mpad, ldc, p(c->L), c->Lld, Npad,
                                       p(c->invD) + (pl.seg_c0[q] / NB) * NB * NB, pl.seg_c0[q], pl.seg_w[q]);
-    } else if (solve_dag_on && keep == 0 && Mpad / NB > 32 && panel_fits(Npad, Mpad) && c->cur == c->stream)
-        trc = solve_dag_panel<T>(c, p(c->L), Npad, c->Lld, p(c->invD), (int*)((double*)c->scal.p + SC_STALL), p(c->Vt), ldc, Mpad, 1);
-    else {
+    } else if (solve_dag_on && keep == 0 && Mpad / NB > 32 && panel_fits(Npad, Mpad) && c->cur == c->stream) {
+        // (a narrow last tile: every tile row leaves it out of the list, the tail kernel solves its columns -- as in
+        // fit_and_solve, so that the two forms stay the same arithmetic)
+        const int64_t r = c->N % NB, N1 = Npad - NB;
+        const bool narrow = r > 0 && r <= 64 && N1 >= 2048 && Mpad >= 2048 && env_switch("ALGP_TAIL_COLS", true);
+        // the tile row in which fit_and_solve carries y - ybar (a last tile with padding rows) keeps every column here too
+        const int64_t short_rows = !narrow ? 0 : (c->M < Mpad ? Mpad - NB : Mpad);
+        trc = solve_dag_panel<T>(c, p(c->L), Npad, c->Lld, p(c->invD), (int*)((double*)c->scal.p + SC_STALL), p(c->Vt), ldc, Mpad, 1,
+                                 (int)(short_rows / NB));
+        if (short_rows > 0 && trc == ALGP_OK)
+            trc = tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), short_rows, ldc, p(c->L), c->Lld, Npad, p(c->invD) + (N1 / NB) * NB * NB,
+                                      N1, (int)round_up(r, 16));
+    } else {
         // a from-scratch solve of more than 320 tile rows: its launches leave the rows' sums of v^2 and v z per column tile
         // (utils.py:301-304 needs nothing else of V^T), the 8 GB pass over V^T at config 4 falls away
         T* stat = nullptr;
@@ -304,10 +314,19 @@ int Impl<T>::fit_and_solve(algp_ctx* c) {
         pn.z_row = c->M;
         ALGP_HIP(hipMemcpyAsync(p(c->Vt) + c->M * c->ldv, c->y0.p, sizeof(T) * c->Npad, hipMemcpyDeviceToDevice, c->stream));
     }
+    // A narrow last tile (N = 10 000: 16 of 128 columns) costs every panel tile row 79 K-steps of the list for 16 columns --
+    // 2.5 % of the panel's work.  The tile rows that do not carry z leave that column tile out (DagShape::pshort) and the
+    // tail kernel solves the r columns behind the launch (one pass over the rank's V^T: 0.2 ms for 12 500 rows).
+    const int64_t r = c->N % NB, N1 = c->Npad - NB;
+    if (r > 0 && r <= 64 && N1 >= 2048 && c->Mpad >= 2048 && env_switch("ALGP_TAIL_COLS", true))
+        pn.short_rows = pn.z_row >= 0 ? c->Mpad - NB : c->Mpad;
     ALGP_TRY(factorize(c, 0, &pn));
     if (!pn.done) {
         if (pn.z_row >= 0) ALGP_HIP(hipMemsetAsync(p(c->Vt) + pn.z_row * c->ldv, 0, sizeof(T) * c->Npad, c->stream));
         ALGP_TRY(solve_run(c, pl));
+    } else if (pn.short_rows > 0) {
+        ALGP_TRY(tail_cols_launch<T>(c, ALGP_PROF_TAIL_COLS, p(c->Vt), pn.short_rows, c->ldv, p(c->L), c->Lld, c->Npad,
+                                     p(c->invD) + (N1 / NB) * NB * NB, N1, (int)round_up(r, 16)));
     }
     return solve_finish(c, 0, nullptr, pl);
 }

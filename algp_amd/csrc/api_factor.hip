@@ -22,7 +22,7 @@ int Impl<T>::factor_resident(algp_ctx* c, T* A, int64_t n, int64_t npad, T* invD
     ALGP_HIP(hipMemsetAsync(sc + slot_logdet, 0, 2 * sizeof(double), c->stream));
     if (panel && panel_fits(npad, panel->mpad)) {
         ALGP_TRY(cholesky_dag_panel<T>(c, A, npad, ld, invD, sc + slot_logdet, (int*)(sc + slot_info), panel->P, panel->ldp,
-                                       panel->mpad, panel->mode));
+                                       panel->mpad, panel->mode, (int)(panel->short_rows / NB)));
         panel->done = true;
         if (panel->mode == 2 && panel->inv_out && c->stream2 && c->cur == c->stream) {
             hipEvent_t ready = sync_event_api(c, 20), done = sync_event_api(c, 21);

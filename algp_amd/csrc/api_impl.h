@@ -44,6 +44,8 @@ struct Impl {
         bool inv_enqueued = false; // the launch, beside the substitutions and read-backs that follow on the main stream
         int64_t z_row = -1;        // this row of P holds y - ybar (mode 1: a padding row; mode 2: a dense tile row behind the identity):
                                    // z^T = (y - ybar)^T L^-T comes out of the launch too
+        int64_t short_rows = 0;    // mode 1: the first short_rows rows (a multiple of 128) leave their last column tile to the caller
+                                   // (the tail kernel solves a narrow last tile's columns afterwards: fit_and_solve)
     };
     static bool panel_fits(int64_t npad, int64_t mpad);
     static int factor_resident(algp_ctx* c, T* A, int64_t n, int64_t npad, T* invD, int slot_logdet, int slot_info,

@@ -625,9 +625,14 @@ struct DagSchedule {
 struct DagShape {
     int nt = 0, mt = 0, mode = 0;
     bool solve_only = false;
+    // mode 1, round 6: the first `pshort` panel tile rows leave their LAST column tile out of the list -- a train set that ends a
+    // few columns into that tile has them solved by the tail kernel afterwards (api_candidates.hip: fit_and_solve), the list
+    // does not pay 79 K-steps per tile row for 16 columns.  (The tile row that carries y - ybar keeps every column: z is whole.)
+    int pshort = 0;
+    int pcols(int e) const { return (mode == 1 && e < pshort) ? nt - 1 : nt; }
     // mode 2: tile rows behind the nt identity rows are dense (mt = nt + 1 in algp_fit_step: the row that carries y - ybar -> z)
     int pstart(int e) const { return (mode == 2 && e < nt) ? e : 0; }      // first non-zero tile column of panel row e
-    bool operator==(const DagShape& o) const { return nt == o.nt && mt == o.mt && mode == o.mode && solve_only == o.solve_only; }
+    bool operator==(const DagShape& o) const { return nt == o.nt && mt == o.mt && mode == o.mode && solve_only == o.solve_only && pshort == o.pshort; }
 };
 
 constexpr int DAG_FAR8 = 4, DAG_FAR16 = 16;                    // see the batches in dag_build_schedule
@@ -720,7 +725,7 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
             }
         }
         auto row_task = [&](int i) {
-            if (k + 1 >= nt) {                                               // last column: nothing to update to its right
+            if (k + 1 >= (i >= nt ? shape.pcols(i - nt) : nt)) {             // the row's last column: nothing to update to its right
                 const int tr = add(DAG_TRSM, i, k, k, k + 1, D_OP + D_OVH);
                 edge(d, tr);
                 edge(last_writer[(size_t)i * nt + k], tr);
@@ -749,7 +754,7 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
         if (!solve_only)
             for (int i = k + 3; i < nt; ++i) row_task(i);
         for (int e = 0; e < mt; ++e)                                         // panel rows: always ticketed, from their first column on
-            if (shape.pstart(e) <= k) row_task(nt + e);
+            if (shape.pstart(e) <= k && k < shape.pcols(e)) row_task(nt + e);
         auto upd = [&](int i, int j, int k0, int k1) {
             const int u = add(DAG_UPD, i, j, k0, k1, D_OVH + D_OP * (k1 - k0));
             edge(last_writer[(size_t)i * nt + j], u);
@@ -783,7 +788,7 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
             if (k0 < 0) return;
             for (int e = 0; e < mt; ++e) {
                 const int ps = shape.pstart(e);
-                if (ps < k + 1) upd(nt + e, j, std::max(k0, ps), k + 1);
+                if (ps < k + 1 && j < shape.pcols(e)) upd(nt + e, j, std::max(k0, ps), k + 1);
             }
         };
         // A panel row is on nobody's critical path: the single steps of its tile (i, j) -- columns [kf, j-1), one to four of
@@ -793,7 +798,7 @@ void dag_build_schedule(const DagShape& shape, int W, int workers, DagSchedule& 
             const int kf = batched_until(j, W);
             for (int e = 0; e < mt; ++e) {
                 const int k0 = std::max(kf, shape.pstart(e));
-                if (k0 < j - 1) upd(nt + e, j, k0, j - 1);
+                if (k0 < j - 1 && j < shape.pcols(e)) upd(nt + e, j, k0, j - 1);
             }
         };
         if (k + 2 < nt) panel_near(k + 2);
@@ -953,7 +958,7 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
     const size_t ver_off = sizeof(double) * 128 * nt + sizeof(int) * ((DAG_CTRL + 3) / 4 * 4 + 5 * (size_t)nt);
     DagCache* dc = nullptr;
     for (auto& e : c->dag_cache)
-        if (e.nt == nt && e.mt == mt && e.mode == shape.mode && e.solve_only == (shape.solve_only ? 1 : 0)) dc = &e;
+        if (e.nt == nt && e.mt == mt && e.mode == shape.mode && e.solve_only == (shape.solve_only ? 1 : 0) && e.pshort == shape.pshort) dc = &e;
     if (!dc) {
         hipDeviceProp_t prop;
         ALGP_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -971,6 +976,7 @@ static int dag_launch(algp_ctx* c, const DagShape& shape, T* A, int64_t ld, T* i
         e.mt = mt;
         e.mode = shape.mode;
         e.solve_only = shape.solve_only ? 1 : 0;
+        e.pshort = shape.pshort;
         e.workers = workers;
         e.ntasks = (int)sched.tasks.size();
         ALGP_TRY(ensure(c, e.tasks, sizeof(DagTask) * std::max<size_t>(sched.tasks.size(), 1)));
@@ -1055,29 +1061,31 @@ template int cholesky_dag<float>(algp_ctx*, float*, int64_t, int64_t, float*, do
 // (mode 1: dense rows, the candidates' B^T -> V^T; mode 2: P = I, npad x npad -> L^-T, zero tiles never touched).
 template <typename T>
 int cholesky_dag_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info, T* P, int64_t ldp,
-                       int64_t mpad, int mode) {
+                       int64_t mpad, int mode, int pshort) {
     DagShape sh;
     sh.nt = (int)(npad / NB);
     sh.mt = (int)(mpad / NB);
     sh.mode = mode;
+    sh.pshort = mode == 1 ? pshort : 0;
     return dag_launch<T>(c, sh, A, ld, invD, P, ldp, logdet_acc, info);
 }
-template int cholesky_dag_panel<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*, double*, int64_t, int64_t, int);
-template int cholesky_dag_panel<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*, float*, int64_t, int64_t, int);
+template int cholesky_dag_panel<double>(algp_ctx*, double*, int64_t, int64_t, double*, double*, int*, double*, int64_t, int64_t, int, int);
+template int cholesky_dag_panel<float>(algp_ctx*, float*, int64_t, int64_t, float*, double*, int*, float*, int64_t, int64_t, int, int);
 
 // P <- P L^-T against a factor that is final (same task list without the factorisation's own tasks)
 template <typename T>
 int solve_dag_panel(algp_ctx* c, const T* L, int64_t npad, int64_t ld, const T* invD, int* info, T* P, int64_t ldp, int64_t mpad,
-                    int mode) {
+                    int mode, int pshort) {
     DagShape sh;
     sh.nt = (int)(npad / NB);
     sh.mt = (int)(mpad / NB);
     sh.mode = mode;
+    sh.pshort = mode == 1 ? pshort : 0;
     sh.solve_only = true;
     return dag_launch<T>(c, sh, const_cast<T*>(L), ld, const_cast<T*>(invD), P, ldp, (double*)nullptr, info);
 }
-template int solve_dag_panel<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, int*, double*, int64_t, int64_t, int);
-template int solve_dag_panel<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, int*, float*, int64_t, int64_t, int);
+template int solve_dag_panel<double>(algp_ctx*, const double*, int64_t, int64_t, const double*, int*, double*, int64_t, int64_t, int, int);
+template int solve_dag_panel<float>(algp_ctx*, const float*, int64_t, int64_t, const float*, int*, float*, int64_t, int64_t, int, int);
 
 void dag_release(algp_ctx* c) {
     for (auto& e : c->dag_cache) {

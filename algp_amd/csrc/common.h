@@ -60,7 +60,7 @@ struct PickRec {           // one committed greedy pick, host side (the device k
 
 struct DagCache {          // device copy of one task list of the dependency-driven Cholesky (chol_dag.hip)
     int64_t nt;
-    int mt = 0, mode = 0, solve_only = 0;   // the row panel carried below the factor (DagShape)
+    int mt = 0, mode = 0, solve_only = 0, pshort = 0;   // the row panel carried below the factor (DagShape)
     DevBuf tasks;
     DevBuf init;           // template of the per-launch state for lists whose tiles do not all start at version 0 (or null)
     int ntasks;
@@ -389,10 +389,10 @@ bool dag_enabled();       // $ALGP_CHOL_DAG != 0
 template <typename T>
 // (mode 2: the identity's nt tile rows may be followed by dense tile rows -- mpad > npad)
 int cholesky_dag_panel(algp_ctx* c, T* A, int64_t npad, int64_t ld, T* invD, double* logdet_acc, int* info, T* P, int64_t ldp,
-                       int64_t mpad, int mode);
+                       int64_t mpad, int mode, int pshort = 0);
 template <typename T>
 int solve_dag_panel(algp_ctx* c, const T* L, int64_t npad, int64_t ld, const T* invD, int* info, T* P, int64_t ldp, int64_t mpad,
-                    int mode);
+                    int mode, int pshort = 0);
 // X (mpad x npad, ld ldx) <- X * L^-T, in place
 template <typename T>
 // stat_out (with stat_w; or null): where every row takes the left-looking order from column 0 (more than 320 tile rows), the

@@ -219,3 +219,39 @@ def test_fit_step_with_the_identity_panel_against_the_three_calls_and_the_oracle
         assert abs(mll - f0 * N) <= tol * abs(f0 * N)
         assert np.max(np.abs(g - want) / np.maximum(1.0, np.abs(want))) <= tol
     c.close()
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-9), (np.float32, 2e-3)], ids=['f64', 'f32'])
+@pytest.mark.parametrize('N,M', [(2100, 4001), (2064, 4096), (2112, 2100), (2113, 4001)],
+                         ids=['r52_z_in_the_last_tile', 'r16_no_padding_row', 'r64', 'r65_every_column_in_the_list'])
+def test_fit_and_solve_leaves_a_narrow_last_tile_to_the_tail_kernel(monkeypatch, dtype, tol, N, M):
+    """Round 6: with a train set that ends r <= 64 columns into its last 128-column tile, the panel's tile rows -- all but the
+    one that carries y - ybar, or all of them when the candidates fill their last tile -- leave that column tile out of the
+    task list (DagShape::pshort) and the tail kernel solves the r columns behind the launch.  Posterior against the oracle
+    (utils.py:293-319), against the list with every column ($ALGP_TAIL_COLS=0), z / log-determinant unchanged; r = 65: no
+    tail launch."""
+    rng = np.random.RandomState(N * 7 + M)
+    pool, A, y, var, cidx = _field(N, M, rng, side=50)
+    samp = np.sort(rng.permutation(M)[:160])
+    ref = O.posterior_chol(HYP, pool[A], y, pool[cidx[samp]], var)
+    c = _ctx(dtype, pool, A, y, var)
+    c.set_candidates(cidx, prior_includes_noise=False)
+    c.prof_enable(True)
+    c.prof_reset()
+    c.fit_and_solve()
+    assert c.prof_get('dag_panel')['launches'] == 1
+    assert c.prof_get('tail_cols')['launches'] == (1 if N % 128 <= 64 else 0)
+    c.prof_enable(False)
+    mu1, pv1 = c.posterior()
+    ld1, a1 = c.logdet(), c.alpha()
+    scale = max(1.0, np.max(np.abs(ref['mu'])))
+    assert np.max(np.abs(mu1[samp] - ref['mu'])) <= tol * scale
+    assert np.max(np.abs(pv1[samp] - ref['var'])) <= tol * max(1.0, np.max(np.abs(ref['var'])))
+    assert np.all(np.isfinite(mu1)) and np.all(np.isfinite(pv1))
+    monkeypatch.setenv('ALGP_TAIL_COLS', '0')
+    c.fit_and_solve()
+    mu0, pv0 = c.posterior()
+    loose = 2e-11 if dtype == np.float64 else 2e-4
+    assert np.max(np.abs(mu1 - mu0)) <= loose * scale and np.max(np.abs(pv1 - pv0)) <= loose
+    assert c.logdet() == ld1 and np.array_equal(c.alpha(), a1)              # the factor and z do not depend on the panel's shape
+    c.close()

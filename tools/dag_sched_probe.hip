@@ -71,10 +71,11 @@ struct Replay {
         };
         if (i >= nt + sh.mt || j >= nt) return bad("tile outside the matrix");
         if (i >= nt && (j < sh.pstart(i - nt) || k0 < sh.pstart(i - nt))) return bad("a panel row touched left of its first column");
+        if (i >= nt && j >= sh.pcols(i - nt)) return bad("a short panel row touched its last column tile");
         if (t.type == DAG_TU) {
             // TRSM(i,k), then -- a wait in the middle of the task, the workgroup held -- UPD(i,k+1,k)
             const int k = j;
-            if (k + 1 >= nt) return bad("TU in the last column");
+            if (k + 1 >= (i >= nt ? sh.pcols(i - nt) : nt)) return bad("TU in the row's last column");
             if (v(i, k) != k) return bad("tile (i,k) is not at version k");
             if (v(k, k) < k + 1) return bad("diagonal block not factored");
             v(i, k) = k + 1;
@@ -112,7 +113,7 @@ static bool check(const DagShape& sh, int W, int workers) {
     }
     for (int i = 0; i < nt + sh.mt; ++i)
         for (int j = (i < nt ? 0 : sh.pstart(i - nt)); j <= (i < nt ? i : nt - 1); ++j)
-            if (r.v(i, j) != j + 1) {
+            if (r.v(i, j) != ((i >= nt && j >= sh.pcols(i - nt)) ? 0 : j + 1)) {         // a short panel row never touches its last column tile
                 printf("nt %d mt %d mode %d solve_only %d workers %d: tile (%d,%d) ends at version %d\n", nt, sh.mt, sh.mode, (int)sh.solve_only,
                        workers, i, j, r.v(i, j));
                 return false;
@@ -151,18 +152,27 @@ int main(int argc, char** argv) {
                             sh.nt = nt; sh.mt = mt; sh.mode = mode; sh.solve_only = so != 0;
                             if (!check(sh, W, workers)) return 1;
                             ++n;
+                            // round 6: dense panels whose tile rows (all, or all but the one that carries z) leave the last column tile out
+                            if (mode == 1)
+                                for (int pshort : {mt, mt - 1}) {
+                                    if (pshort < 1) continue;
+                                    sh.pshort = pshort;
+                                    if (!check(sh, W, workers)) return 1;
+                                    ++n;
+                                }
                         }
                     }
         printf("CHECK OK: %d panel schedules (N/128 = %d..%d)\n", n, lo, hi);
         return 0;
     }
     if (argc > 5 && !strcmp(argv[1], "--check-shape")) {
-        // one shape, e.g. the largest the library sends: --check-shape NT MT MODE SOLVE_ONLY
+        // one shape, e.g. the largest the library sends: --check-shape NT MT MODE SOLVE_ONLY [PSHORT]
         DagShape sh;
         sh.nt = atoi(argv[2]); sh.mt = atoi(argv[3]); sh.mode = atoi(argv[4]); sh.solve_only = atoi(argv[5]) != 0;
+        sh.pshort = argc > 6 ? atoi(argv[6]) : 0;                  // [PSHORT]: panel tile rows without their last column tile
         for (int workers : {512, 2 * DAG_TEAM + 1})
             if (!check(sh, 2, workers)) return 1;
-        printf("CHECK OK: shape nt %d mt %d mode %d solve_only %d\n", sh.nt, sh.mt, sh.mode, (int)sh.solve_only);
+        printf("CHECK OK: shape nt %d mt %d mode %d solve_only %d pshort %d\n", sh.nt, sh.mt, sh.mode, (int)sh.solve_only, sh.pshort);
         return 0;
     }
     // dag_sched_probe NT [MT MODE SOLVE_ONLY]
