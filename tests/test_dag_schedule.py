@@ -24,7 +24,7 @@ def test_ticket_list_is_a_valid_sequential_order_for_every_size(tmp_path):
     # lists that carry a row panel below the factor (the candidates' rows of algp_fit_and_solve, the identity that becomes
     # L^-T), with and without the factorisation's own tasks: same replay, panel rows starting at their first column
     r = subprocess.run([exe, '--check-panel', '8', '40'], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and 'CHECK OK: 1881 panel schedules' in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
+    assert r.returncode == 0 and 'CHECK OK: 2574 panel schedules' in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
     # the panel at its shipped maximum (400 tile rows = 51 200 candidates) under config 4's factor, folded and alone, and the
     # identity panel of a fit iteration at N = 10 000
     # (round 6: and with the panel's tile rows -- all but the one that carries z, or all -- leaving their last column tile to the tail kernel)
